@@ -1,0 +1,267 @@
+/*
+ * suma_detmath.h -- deterministic single-precision elementary functions.
+ *
+ * WHY THIS EXISTS.  The reference computes atan/asin/acos/sin/exp/log inside GLSL shaders
+ * (e.g. src/shader/gen_vertexmap.vert:80-81, update_surfels.vert:116-121,238-243), where the
+ * GL driver picks the implementation and its last-ulp behaviour.  The projective pipeline then
+ * feeds those values through floor() to obtain pixel indices, so a 1-ulp difference between two
+ * implementations flips integer outputs (pixel assignment, surfel counts).  To make "bit-exact
+ * surfel indices/counts" a testable property between the CPU oracle and the gfx950 kernels,
+ * the transcendental functions are part of the *specification*: both sides evaluate the very
+ * same sequence of IEEE-754 binary32 +,-,*,/,sqrt operations (no FMA contraction: every
+ * translation unit including this header is compiled with -ffp-contract=off; hipcc's default
+ * correctly rounded fp32 divide/sqrt is relied upon and checked by tests/test_detmath.py).
+ *
+ * Algorithms: classic Cephes single-precision kernels (S. Moshier, public domain algorithms:
+ * atanf/asinf/sinf/expf/logf range reductions + minimax polynomials), restated here.
+ * Accuracy (measured in tests/test_detmath.py against libm in double): <= 2 ulp on the
+ * domains used by the pipeline.
+ *
+ * C99 / C++ / HIP compatible, header-only.
+ */
+#ifndef SUMA_DETMATH_H_
+#define SUMA_DETMATH_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define SUMA_HD __host__ __device__ static inline
+#else
+#define SUMA_HD static inline
+#endif
+
+#define SUMA_PI_F 3.14159265358979323846f
+#define SUMA_PI_2_F 1.57079632679489661923f
+#define SUMA_PI_4_F 0.78539816339744830962f
+/* the literal used by every projection in the reference (gen_vertexmap.vert:19) */
+#define SUMA_INV_PI_F 0.31830988618379067154f
+/* GLSL degrees(): 180/pi */
+#define SUMA_RAD2DEG_F 57.295779513082320877f
+
+SUMA_HD uint32_t sdm_f2u(float f) {
+  uint32_t u;
+  __builtin_memcpy(&u, &f, 4);
+  return u;
+}
+SUMA_HD float sdm_u2f(uint32_t u) {
+  float f;
+  __builtin_memcpy(&f, &u, 4);
+  return f;
+}
+SUMA_HD float sdm_abs(float x) { return sdm_u2f(sdm_f2u(x) & 0x7fffffffu); }
+SUMA_HD int sdm_isnan(float x) { return (sdm_f2u(x) & 0x7fffffffu) > 0x7f800000u; }
+
+/* exact floor for |x| < 2^31, NaN -> NaN, large values returned unchanged */
+SUMA_HD float sdm_floor(float x) {
+  if (!(sdm_abs(x) < 8388608.0f)) return x; /* already integral, inf or NaN */
+  float t = (float)(int32_t)x;              /* truncation */
+  return (t > x) ? (t - 1.0f) : t;
+}
+
+/* round half away from zero (C roundf); the pipeline only feeds near-integers */
+SUMA_HD float sdm_round(float x) {
+  if (!(sdm_abs(x) < 8388608.0f)) return x;
+  float a = sdm_abs(x);
+  float t = (float)(int32_t)(a + 0.5f);
+  if (t - a > 0.5f) t = t - 1.0f; /* guards the a+0.5 rounding case */
+  return (x < 0.0f) ? -t : t;
+}
+
+SUMA_HD float sdm_atan(float xx) {
+  float x = sdm_abs(xx);
+  float y;
+  if (x > 2.414213562373095f) { /* tan(3pi/8) */
+    y = SUMA_PI_2_F;
+    x = -(1.0f / x);
+  } else if (x > 0.4142135623730950f) { /* tan(pi/8) */
+    y = SUMA_PI_4_F;
+    x = (x - 1.0f) / (x + 1.0f);
+  } else {
+    y = 0.0f;
+  }
+  float z = x * x;
+  float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+  p = p * z + 1.99777106478e-1f;
+  p = p * z - 3.33329491539e-1f;
+  p = p * z * x + x;
+  y = y + p;
+  return (xx < 0.0f) ? -y : y;
+}
+
+/* atan2 with the C quadrant conventions; (0,0) -> 0 */
+SUMA_HD float sdm_atan2(float y, float x) {
+  if (sdm_isnan(x) || sdm_isnan(y)) return x + y;
+  if (x == 0.0f) {
+    if (y > 0.0f) return SUMA_PI_2_F;
+    if (y < 0.0f) return -SUMA_PI_2_F;
+    return 0.0f;
+  }
+  float z = sdm_atan(y / x);
+  if (x < 0.0f) {
+    if (y < 0.0f)
+      z = z - SUMA_PI_F;
+    else
+      z = z + SUMA_PI_F;
+  }
+  return z;
+}
+
+SUMA_HD float sdm_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __fsqrt_rn(x);
+#else
+  return __builtin_sqrtf(x);
+#endif
+}
+
+SUMA_HD float sdm_asin(float xx) {
+  float a = sdm_abs(xx);
+  if (!(a <= 1.0f)) return sdm_u2f(0x7fc00000u); /* NaN, also for NaN input */
+  float x, z;
+  int flag = 0;
+  if (a < 1.0e-4f) return xx;
+  if (a > 0.5f) {
+    z = 0.5f * (1.0f - a);
+    x = sdm_sqrt(z);
+    flag = 1;
+  } else {
+    x = a;
+    z = x * x;
+  }
+  float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+  p = p * z + 4.5470025998e-2f;
+  p = p * z + 7.4953002686e-2f;
+  p = p * z + 1.6666752422e-1f;
+  z = p * z * x + x;
+  if (flag) {
+    z = z + z;
+    z = SUMA_PI_2_F - z;
+  }
+  return (xx < 0.0f) ? -z : z;
+}
+
+SUMA_HD float sdm_acos(float x) {
+  if (!(sdm_abs(x) <= 1.0f)) return sdm_u2f(0x7fc00000u);
+  if (x < -0.5f) return SUMA_PI_F - 2.0f * sdm_asin(sdm_sqrt(0.5f * (1.0f + x)));
+  if (x > 0.5f) return 2.0f * sdm_asin(sdm_sqrt(0.5f * (1.0f - x)));
+  return SUMA_PI_2_F - sdm_asin(x);
+}
+
+/* sin / cos for |x| <= 8192 (the pipeline uses [0, pi]) */
+SUMA_HD float sdm_sincos_core(float xx, int want_cos) {
+  const float DP1 = 0.78515625f, DP2 = 2.4187564849853515625e-4f, DP3 = 3.77489497744594108e-8f;
+  const float FOPI = 1.27323954473516f; /* 4/pi */
+  int sign = 1;
+  float x = xx;
+  if (x < 0.0f) {
+    x = -x;
+    if (!want_cos) sign = -1;
+  }
+  if (!(x <= 8192.0f)) return sdm_u2f(0x7fc00000u);
+  int32_t j = (int32_t)(FOPI * x);
+  float y = (float)j;
+  if (j & 1) {
+    j += 1;
+    y += 1.0f;
+  }
+  j &= 7;
+  if (j > 3) {
+    sign = -sign;
+    j -= 4;
+  }
+  if (want_cos && j > 1) sign = -sign;
+  x = ((x - y * DP1) - y * DP2) - y * DP3;
+  float z = x * x;
+  float r;
+  int use_cos_poly = want_cos ? !(j == 1 || j == 2) : (j == 1 || j == 2);
+  if (use_cos_poly) {
+    float p = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
+    p = p * z + 4.166664568298827e-2f;
+    r = p * z * z;
+    r = r - 0.5f * z;
+    r = r + 1.0f;
+  } else {
+    float p = -1.9515295891e-4f * z + 8.3321608736e-3f;
+    p = p * z - 1.6666654611e-1f;
+    r = p * z * x + x;
+  }
+  return (sign < 0) ? -r : r;
+}
+SUMA_HD float sdm_sin(float x) { return sdm_sincos_core(x, 0); }
+SUMA_HD float sdm_cos(float x) { return sdm_sincos_core(x, 1); }
+
+/* 2^n * x for results in the normal range, exact */
+SUMA_HD float sdm_ldexp(float x, int32_t n) {
+  /* split the scaling so each factor is a normal power of two */
+  while (n > 127) {
+    x = x * sdm_u2f(0x7f000000u); /* 2^127 */
+    n -= 127;
+  }
+  while (n < -126) {
+    x = x * sdm_u2f(0x00800000u); /* 2^-126 */
+    n += 126;
+  }
+  return x * sdm_u2f((uint32_t)(n + 127) << 23);
+}
+
+SUMA_HD float sdm_exp(float xx) {
+  if (sdm_isnan(xx)) return xx;
+  if (xx > 88.72283905206835f) return sdm_u2f(0x7f800000u);
+  if (xx < -103.278929903431851103f) return 0.0f;
+  const float LOG2EF = 1.44269504088896341f;
+  const float C1 = 0.693359375f, C2 = -2.12194440e-4f;
+  float x = xx;
+  float z = sdm_floor(LOG2EF * x + 0.5f);
+  x = x - z * C1;
+  x = x - z * C2;
+  int32_t n = (int32_t)z;
+  z = x * x;
+  float p = 1.9875691500e-4f * x + 1.3981999507e-3f;
+  p = p * x + 8.3334519073e-3f;
+  p = p * x + 4.1665795894e-2f;
+  p = p * x + 1.6666665459e-1f;
+  p = p * x + 5.0000001201e-1f;
+  z = p * z + x + 1.0f;
+  return sdm_ldexp(z, n);
+}
+
+SUMA_HD float sdm_log(float xx) {
+  if (sdm_isnan(xx)) return xx;
+  if (xx < 0.0f) return sdm_u2f(0x7fc00000u);
+  if (xx == 0.0f) return sdm_u2f(0xff800000u);
+  if (sdm_f2u(xx) == 0x7f800000u) return xx;
+  /* frexp: x = m * 2^e, m in [0.5, 1) */
+  uint32_t u = sdm_f2u(xx);
+  int32_t e = 0;
+  if ((u >> 23) == 0) { /* subnormal: scale up by 2^24 */
+    xx = xx * 16777216.0f;
+    u = sdm_f2u(xx);
+    e = -24;
+  }
+  e += (int32_t)(u >> 23) - 126;
+  float x = sdm_u2f((u & 0x007fffffu) | 0x3f000000u);
+  if (x < 0.707106781186547524f) {
+    e -= 1;
+    x = x + x - 1.0f;
+  } else {
+    x = x - 1.0f;
+  }
+  float z = x * x;
+  float p = 7.0376836292e-2f * x - 1.1514610310e-1f;
+  p = p * x + 1.1676998740e-1f;
+  p = p * x - 1.2420140846e-1f;
+  p = p * x + 1.4249322787e-1f;
+  p = p * x - 1.6668057665e-1f;
+  p = p * x + 2.0000714765e-1f;
+  p = p * x - 2.4999993993e-1f;
+  p = p * x + 3.3333331174e-1f;
+  float y = p * x * z;
+  float fe = (float)e;
+  y = y + -2.12194440e-4f * fe;
+  y = y - 0.5f * z;
+  z = x + y;
+  z = z + 0.693359375f * fe;
+  return z;
+}
+
+#endif /* SUMA_DETMATH_H_ */

@@ -1,0 +1,118 @@
+/*
+ * oracle/o_math.h -- TEST INFRASTRUCTURE (CPU oracle), never shipped or linked by the product.
+ *
+ * Small fp32 vector / matrix helpers with a FIXED operation order, restating the GLSL built-ins
+ * the reference's shaders use (dot, cross, length, normalize, mat4*vec4, mat4*mat4).  The
+ * operation order below IS the specification; the gfx950 kernels restate the same order so the
+ * two can be compared bit for bit.  Compiled with -ffp-contract=off.
+ */
+#ifndef ORACLE_O_MATH_H_
+#define ORACLE_O_MATH_H_
+
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+#include "../include/suma_detmath.h"
+#include "../include/suma_types.h"
+
+#ifdef ORACLE_USE_LIBM
+/* independence cross-check build: glibc transcendental functions instead of the shared
+ * deterministic ones (results then agree only to tolerance, never used for bit parity) */
+#define sdm_atan2 atan2f
+#define sdm_asin asinf
+#define sdm_acos acosf
+#define sdm_sin sinf
+#define sdm_exp expf
+#define sdm_log logf
+#endif
+
+typedef struct {
+  float x, y, z;
+} ov3;
+
+static inline ov3 ov3_make(float x, float y, float z) {
+  ov3 r = {x, y, z};
+  return r;
+}
+static inline float ov3_dot(ov3 a, ov3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline float ov3_len(ov3 a) { return sdm_sqrt(ov3_dot(a, a)); }
+static inline ov3 ov3_sub(ov3 a, ov3 b) { return ov3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline ov3 ov3_add(ov3 a, ov3 b) { return ov3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline ov3 ov3_scale(float s, ov3 a) { return ov3_make(s * a.x, s * a.y, s * a.z); }
+static inline ov3 ov3_divs(ov3 a, float s) { return ov3_make(a.x / s, a.y / s, a.z / s); }
+static inline ov3 ov3_neg(ov3 a) { return ov3_make(-a.x, -a.y, -a.z); }
+/* GLSL normalize(): v / length(v) */
+static inline ov3 ov3_normalize(ov3 a) { return ov3_divs(a, ov3_len(a)); }
+static inline ov3 ov3_cross(ov3 a, ov3 b) {
+  return ov3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+
+/* column-major 4x4 (Eigen::Matrix4f / GLSL mat4): element (row r, col c) = m[4*c + r] */
+/* M * (p, 1) : ((col0*x + col1*y) + col2*z) + col3, xyz rows only */
+static inline ov3 om4_point(const float* m, ov3 p) {
+  ov3 r;
+  r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12];
+  r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13];
+  r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14];
+  return r;
+}
+/* M * (d, 0) */
+static inline ov3 om4_dir(const float* m, ov3 d) {
+  ov3 r;
+  r.x = (m[0] * d.x + m[4] * d.y) + m[8] * d.z;
+  r.y = (m[1] * d.x + m[5] * d.y) + m[9] * d.z;
+  r.z = (m[2] * d.x + m[6] * d.y) + m[10] * d.z;
+  return r;
+}
+/* C = A * B, each element ((a0*b0 + a1*b1) + a2*b2) + a3*b3 */
+static inline void om4_mul(const float* A, const float* B, float* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      C[4 * c + r] =
+          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+}
+/* Inverse of a rigid transform, evaluated in double from the fp32 matrix and rounded once to
+ * fp32: R^T, -R^T t.  (The reference uses Eigen's / GLSL's general inverse on rigid poses,
+ * SurfelMap.cpp:497,875 and update_surfels.vert:197; those agree with this to fp32 rounding.) */
+static inline void om4_rigid_inverse(const float* m, float* out) {
+  double R[9], t[3];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
+  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
+  for (int r = 0; r < 3; ++r) {
+    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
+    out[12 + r] = (float)(-s);
+  }
+  out[3] = out[7] = out[11] = 0.0f;
+  out[15] = 1.0f;
+}
+
+static inline float of_clamp(float x, float lo, float hi) {
+  float t = (x < lo) ? lo : x; /* max(x, lo) */
+  return (t > hi) ? hi : t;    /* min(t, hi) */
+}
+static inline float of_min(float a, float b) { return (b < a) ? b : a; }
+static inline float of_max(float a, float b) { return (a < b) ? b : a; }
+
+/* color.glsl:31-37 pack() */
+static inline float o_pack(float r, float g, float b) {
+  int32_t rgb = (int32_t)sdm_round(r * 255.0f);
+  rgb = (rgb << 8) + (int32_t)sdm_round(g * 255.0f);
+  rgb = (rgb << 8) + (int32_t)sdm_round(b * 255.0f);
+  return (float)rgb;
+}
+
+/* color_map.glsl:8-17: the movable classes the shaders single out */
+static inline int o_is_dynamic_label(float label) {
+  return label == 10.0f || label == 11.0f || label == 13.0f || label == 15.0f || label == 18.0f || label == 20.0f ||
+         label == 30.0f || label == 31.0f || label == 32.0f;
+}
+
+/* 24-bit unorm depth of a window-space z in [0,1] (GL_DEPTH24_STENCIL8 renderbuffers,
+ * Preprocessing.cpp:56, SurfelMap.cpp:103,113,172) */
+static inline uint32_t o_depth24(float zw) { return (uint32_t)(zw * 16777215.0f + 0.5f); }
+
+#endif

@@ -1,0 +1,332 @@
+"""TEST INFRASTRUCTURE -- ctypes loader for the CPU oracle (oracle/libsuma_oracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
+product package never does.  The oracle is a CPU restatement of the reference's GLSL path
+(parity unpinned: the reference ships no golden vectors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from semantic_suma_amd.types import ACC_WORDS, SURFEL_DTYPE, IcpStats, SumaParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+c_f4p = C.POINTER(C.c_float)
+c_f8p = C.POINTER(C.c_double)
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle with gcc (seconds)."""
+    tgt = os.path.join(_HERE, "libsuma_oracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    srcs += [os.path.join(_HERE, "..", "include", f) for f in ("suma_detmath.h", "suma_types.h")]
+    if force or not os.path.exists(tgt) or any(os.path.getmtime(s) > os.path.getmtime(tgt) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
+
+
+def lib(variant: str = ""):
+    """variant '' = deterministic-math oracle, 'libm' = glibc transcendental functions."""
+    if variant in _LIBS:
+        return _LIBS[variant]
+    name = "libsuma_oracle.so" if not variant else f"libsuma_oracle_{variant}.so"
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        build()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.ora_create.restype = vp
+    L.ora_create.argtypes = [C.POINTER(SumaParams)]
+    L.ora_destroy.argtypes = [vp]
+    L.ora_set_params.argtypes = [vp, C.POINTER(SumaParams)]
+    L.ora_set_threads.argtypes = [vp, C.c_int]
+    L.ora_frame_create.restype = vp
+    L.ora_frame_create.argtypes = [C.c_uint32, C.c_uint32]
+    L.ora_frame_destroy.argtypes = [vp]
+    L.ora_frame_map.restype = vp
+    L.ora_frame_map.argtypes = [vp, C.c_int]
+    L.ora_frame_copy.argtypes = [vp, vp]
+    L.ora_preprocess.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_uint32, vp]
+    L.ora_icp_jacobian_products.restype = C.c_double
+    L.ora_icp_jacobian_products.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(IcpStats)]
+    L.ora_icp_minimize.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(IcpStats)]
+    L.ora_map_reset.argtypes = [vp]
+    L.ora_map_update.argtypes = [vp, vp, vp]
+    L.ora_map_render.argtypes = [vp, vp, vp, C.c_float, vp]
+    L.ora_map_render_active.argtypes = [vp, vp, C.c_float]
+    L.ora_map_render_inactive.argtypes = [vp, vp, C.c_float]
+    L.ora_map_render_composed.argtypes = [vp, vp, vp, C.c_float]
+    L.ora_map_frame.restype = vp
+    L.ora_map_frame.argtypes = [vp, C.c_int]
+    L.ora_map_update_poses.argtypes = [vp, vp, C.c_uint32]
+    L.ora_map_size.restype = C.c_uint32
+    L.ora_map_size.argtypes = [vp]
+    L.ora_map_timestamp.restype = C.c_uint32
+    L.ora_map_timestamp.argtypes = [vp]
+    L.ora_map_surfels.restype = vp
+    L.ora_map_surfels.argtypes = [vp]
+    L.ora_map_upload.argtypes = [vp, vp, C.c_uint32, C.c_uint32]
+    for n in ("ora_map_index_map", "ora_map_radius_conf", "ora_map_integrated"):
+        getattr(L, n).restype = vp
+        getattr(L, n).argtypes = [vp]
+    for n in ("ora_map_last_updated_count", "ora_map_last_new_count", "ora_map_cached_surfels"):
+        getattr(L, n).restype = C.c_uint32
+        getattr(L, n).argtypes = [vp]
+    L.ora_map_submap_origin.argtypes = [vp, vp]
+    L.ora_pipeline_create.restype = vp
+    L.ora_pipeline_create.argtypes = [C.POINTER(SumaParams)]
+    L.ora_pipeline_destroy.argtypes = [vp]
+    L.ora_pipeline_ctx.restype = vp
+    L.ora_pipeline_ctx.argtypes = [vp]
+    L.ora_pipeline_process_scan.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int32]
+    L.ora_pipeline_pose.argtypes = [vp, vp]
+    L.ora_pipeline_last_increment.argtypes = [vp, vp]
+    L.ora_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
+    L.ora_pipeline_frame.restype = vp
+    L.ora_pipeline_frame.argtypes = [vp, C.c_int]
+    L.ora_se3_exp.argtypes = [vp, vp]
+    L.ora_solve6.argtypes = [vp, vp, vp]
+    _LIBS[variant] = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _view(ptr, shape, dtype):
+    n = int(np.prod(shape))
+    buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+class OracleFrame:
+    """Host-side Frame: three H x W x 4 float32 maps (row 0 = bottom row)."""
+
+    def __init__(self, L, width, height, handle=None):
+        self.L, self.width, self.height = L, width, height
+        self.owned = handle is None
+        self.h = L.ora_frame_create(width, height) if handle is None else handle
+
+    def map(self, which) -> np.ndarray:
+        return _view(self.L.ora_frame_map(self.h, which), (self.height, self.width, 4), np.float32)
+
+    @property
+    def vertex(self):
+        return self.map(0)
+
+    @property
+    def normal(self):
+        return self.map(1)
+
+    @property
+    def semantic(self):
+        return self.map(2)
+
+    def set(self, vertex, normal, semantic):
+        self.vertex[...] = vertex
+        self.normal[...] = normal
+        self.semantic[...] = semantic
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            self.L.ora_frame_destroy(self.h)
+            self.h = None
+
+
+class Oracle:
+    """One oracle context = Preprocessing + Frame2Model + LieGaussNewton + SurfelMap state."""
+
+    def __init__(self, params: SumaParams, variant: str = "", threads: int = 1, handle=None, keepalive=None):
+        self.L = lib(variant)
+        self.params = params
+        self.owned = handle is None
+        self.h = self.L.ora_create(C.byref(params)) if handle is None else handle
+        self._keepalive = keepalive
+        if threads != 1:
+            self.L.ora_set_threads(self.h, threads)
+
+    def __del__(self):
+        if getattr(self, "owned", False) and self.h:
+            self.L.ora_destroy(self.h)
+            self.h = None
+
+    def set_params(self, params):
+        self.params = params
+        self.L.ora_set_params(self.h, C.byref(params))
+
+    def set_threads(self, n):
+        self.L.ora_set_threads(self.h, n)
+
+    def frame(self, model=False) -> OracleFrame:
+        p = self.params
+        return OracleFrame(self.L, p.model_width if model else p.data_width, p.model_height if model else p.data_height)
+
+    # -- Preprocessing::process
+    def preprocess(self, points, labels, probs, timestamp, out: OracleFrame):
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        probs = None if probs is None else np.ascontiguousarray(probs, dtype=np.float32)
+        self.L.ora_preprocess(self.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0], timestamp, out.h)
+        return out
+
+    # -- Frame2Model::jacobianProducts
+    def jacobian_products(self, current, model, pose, iteration=0):
+        pose = np.ascontiguousarray(np.asarray(pose, dtype=np.float64).T)  # column-major
+        acc = np.zeros(ACC_WORDS, dtype=np.int64)
+        JtJ = np.zeros((6, 6), dtype=np.float64)
+        Jtr = np.zeros(6, dtype=np.float64)
+        st = IcpStats()
+        F = self.L.ora_icp_jacobian_products(self.h, current.h, model.h, _ptr(pose), iteration, _ptr(acc), _ptr(JtJ),
+                                             _ptr(Jtr), C.byref(st))
+        return F, acc, JtJ, Jtr, st
+
+    # -- LieGaussNewton::minimize
+    def minimize(self, current, model, T0, history_cap=64):
+        T0 = np.ascontiguousarray(np.asarray(T0, dtype=np.float64).T)
+        T = np.zeros((4, 4), dtype=np.float64)
+        hist = np.zeros((history_cap, 4, 4), dtype=np.float64)
+        nh = C.c_uint32(0)
+        st = IcpStats()
+        self.L.ora_icp_minimize(self.h, current.h, model.h, _ptr(T0), _ptr(T), _ptr(hist), history_cap, C.byref(nh),
+                                C.byref(st))
+        n = min(nh.value, history_cap)
+        return T.T.copy(), hist[:n].transpose(0, 2, 1).copy(), st
+
+    # -- SurfelMap
+    def map_reset(self):
+        self.L.ora_map_reset(self.h)
+
+    def map_update(self, pose, frame):
+        pose = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).T)
+        self.L.ora_map_update(self.h, _ptr(pose), frame.h)
+
+    def map_render(self, pose_old, pose_new, conf_threshold, out):
+        po = np.ascontiguousarray(np.asarray(pose_old, dtype=np.float32).T)
+        pn = np.ascontiguousarray(np.asarray(pose_new, dtype=np.float32).T)
+        self.L.ora_map_render(self.h, _ptr(po), _ptr(pn), conf_threshold, out.h)
+        return out
+
+    def map_render_active(self, pose, conf_threshold):
+        p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).T)
+        self.L.ora_map_render_active(self.h, _ptr(p), conf_threshold)
+
+    def map_render_inactive(self, pose, conf_threshold):
+        p = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).T)
+        self.L.ora_map_render_inactive(self.h, _ptr(p), conf_threshold)
+
+    def map_render_composed(self, pose_old, pose_new, conf_threshold):
+        po = np.ascontiguousarray(np.asarray(pose_old, dtype=np.float32).T)
+        pn = np.ascontiguousarray(np.asarray(pose_new, dtype=np.float32).T)
+        self.L.ora_map_render_composed(self.h, _ptr(po), _ptr(pn), conf_threshold)
+
+    def map_frame(self, which) -> OracleFrame:
+        p = self.params
+        return OracleFrame(self.L, p.model_width, p.model_height, handle=self.L.ora_map_frame(self.h, which))
+
+    def map_update_poses(self, poses):
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).transpose(0, 2, 1))
+        self.L.ora_map_update_poses(self.h, _ptr(poses), poses.shape[0])
+
+    def map_size(self):
+        return self.L.ora_map_size(self.h)
+
+    def map_timestamp(self):
+        return self.L.ora_map_timestamp(self.h)
+
+    def map_surfels(self) -> np.ndarray:
+        n = self.map_size()
+        if n == 0:
+            return np.zeros(0, dtype=SURFEL_DTYPE)
+        return _view(self.L.ora_map_surfels(self.h), (n,), SURFEL_DTYPE).copy()
+
+    def map_upload(self, surfels, timestamp):
+        surfels = np.ascontiguousarray(surfels, dtype=SURFEL_DTYPE)
+        self.L.ora_map_upload(self.h, _ptr(surfels), surfels.shape[0], timestamp)
+
+    def map_index_map(self):
+        p = self.params
+        return _view(self.L.ora_map_index_map(self.h), (p.data_height, p.data_width), np.uint32).copy()
+
+    def map_radius_conf(self):
+        p = self.params
+        return _view(self.L.ora_map_radius_conf(self.h), (p.data_height, p.data_width, 4), np.float32).copy()
+
+    def map_integrated(self):
+        p = self.params
+        return _view(self.L.ora_map_integrated(self.h), (p.data_height, p.data_width), np.uint8).copy()
+
+    def map_counts(self):
+        return self.L.ora_map_last_updated_count(self.h), self.L.ora_map_last_new_count(self.h)
+
+    def map_cached_surfels(self):
+        return self.L.ora_map_cached_surfels(self.h)
+
+    def map_submap_origin(self):
+        ij = np.zeros(2, dtype=np.int32)
+        self.L.ora_map_submap_origin(self.h, _ptr(ij))
+        return int(ij[0]), int(ij[1])
+
+
+class OraclePipeline:
+    """SurfelMapping::processScan (no loop closures)."""
+
+    def __init__(self, params: SumaParams, variant: str = "", threads: int = 1):
+        self.L = lib(variant)
+        self.params = params
+        self.h = self.L.ora_pipeline_create(C.byref(params))
+        self.ctx = Oracle(params, variant, handle=self.L.ora_pipeline_ctx(self.h), keepalive=self)
+        if threads != 1:
+            self.ctx.set_threads(threads)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ora_pipeline_destroy(self.h)
+            self.h = None
+
+    def process_scan(self, points, labels, probs, fixed_iterations=0):
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.float32)
+        probs = np.ascontiguousarray(probs, dtype=np.float32)
+        self.L.ora_pipeline_process_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0],
+                                         fixed_iterations)
+
+    def pose(self):
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.L.ora_pipeline_pose(self.h, _ptr(T))
+        return T.T.copy()
+
+    def last_increment(self):
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.L.ora_pipeline_last_increment(self.h, _ptr(T))
+        return T.T.copy()
+
+    def last_stats(self):
+        st = IcpStats()
+        self.L.ora_pipeline_last_stats(self.h, C.byref(st))
+        return st
+
+    def frame(self, which) -> OracleFrame:
+        p = self.params
+        w, h = (p.data_width, p.data_height) if which == 0 else (p.model_width, p.model_height)
+        return OracleFrame(self.L, w, h, handle=self.L.ora_pipeline_frame(self.h, which))
+
+
+def se3_exp(x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    T = np.zeros((4, 4), dtype=np.float64)
+    lib().ora_se3_exp(_ptr(x), _ptr(T))
+    return T.T.copy()
+
+
+def solve6(JtJ, Jtr):
+    JtJ = np.ascontiguousarray(np.asarray(JtJ, dtype=np.float64).T)
+    Jtr = np.ascontiguousarray(Jtr, dtype=np.float64)
+    x = np.zeros(6, dtype=np.float64)
+    lib().ora_solve6(_ptr(JtJ), _ptr(Jtr), _ptr(x))
+    return x

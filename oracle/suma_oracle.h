@@ -1,0 +1,99 @@
+/*
+ * oracle/suma_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement of the SuMa++ projective-ICP +
+ * surfel-fusion hot path (reference: PRBonn/semantic_suma, src/core + src/shader).
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures and
+ * cannot be built or run here (needs an OpenGL context, glow, Eigen, gtsam, Qt).  This oracle is
+ * a line-by-line restatement of the GLSL shaders and their host call sites; each function cites
+ * the file:line it follows.  It is pinned only by analytic known-answer tests (tests/test_oracle_kat.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product (semantic_suma_amd/) never links, imports or calls it.
+ */
+#ifndef SUMA_ORACLE_H_
+#define SUMA_ORACLE_H_
+
+#include <stdint.h>
+
+#include "../include/suma_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ora_frame {
+  uint32_t width, height;
+  suma_float4* vertex;
+  suma_float4* normal;
+  suma_float4* semantic;
+} ora_frame;
+
+typedef struct ora_ctx ora_ctx;
+
+ora_ctx* ora_create(const suma_params* p);
+void ora_destroy(ora_ctx* c);
+void ora_set_params(ora_ctx* c, const suma_params* p);
+/* number of OpenMP threads used by the pixel / surfel loops (1 = faithful sequential) */
+void ora_set_threads(ora_ctx* c, int n);
+
+ora_frame* ora_frame_create(uint32_t w, uint32_t h);
+void ora_frame_destroy(ora_frame* f);
+suma_float4* ora_frame_map(ora_frame* f, int which);
+void ora_frame_copy(ora_frame* dst, const ora_frame* src);
+
+/* K1-K3: Preprocessing::process (src/core/Preprocessing.cpp:120-339) */
+void ora_preprocess(ora_ctx* c, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                    uint32_t timestamp, ora_frame* out);
+
+/* K6: Frame2Model::jacobianProducts (src/core/Frame2Model.cpp:136-261).  acc = raw int64 sums
+ * (SUMA_ACC_WORDS), JtJ column-major 6x6. Returns F. */
+double ora_icp_jacobian_products(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double pose[16],
+                                 uint32_t iteration, int64_t* acc, double* JtJ, double* Jtr, suma_icp_stats* st);
+/* LieGaussNewton::minimize (src/core/LieGaussNewton.cpp:13-79): history gets (n_hist) 4x4 doubles */
+void ora_icp_minimize(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
+                      double T_out[16], double* history, uint32_t history_cap, uint32_t* n_hist, suma_icp_stats* st);
+
+/* SurfelMap (src/core/SurfelMap.cpp) */
+void ora_map_reset(ora_ctx* c);
+void ora_map_update(ora_ctx* c, const float pose[16], const ora_frame* frame);
+void ora_map_render(ora_ctx* c, const float pose_old[16], const float pose_new[16], float conf_threshold,
+                    ora_frame* out);
+void ora_map_render_active(ora_ctx* c, const float pose[16], float conf_threshold);
+void ora_map_render_inactive(ora_ctx* c, const float pose[16], float conf_threshold);
+void ora_map_render_composed(ora_ctx* c, const float pose_old[16], const float pose_new[16], float conf_threshold);
+ora_frame* ora_map_frame(ora_ctx* c, int which);
+void ora_map_update_poses(ora_ctx* c, const float* poses16, uint32_t n);
+uint32_t ora_map_size(const ora_ctx* c);
+uint32_t ora_map_timestamp(const ora_ctx* c);
+const suma_surfel* ora_map_surfels(const ora_ctx* c);
+void ora_map_upload(ora_ctx* c, const suma_surfel* s, uint32_t n, uint32_t timestamp);
+/* intermediates of the last update, for stage-by-stage parity */
+const uint32_t* ora_map_index_map(const ora_ctx* c);       /* P, surfel id + 1, 0 = none */
+const suma_float4* ora_map_radius_conf(const ora_ctx* c);  /* P */
+const uint8_t* ora_map_integrated(const ora_ctx* c);       /* P */
+uint32_t ora_map_last_updated_count(const ora_ctx* c);     /* S' */
+uint32_t ora_map_last_new_count(const ora_ctx* c);         /* D  */
+uint32_t ora_map_cached_surfels(const ora_ctx* c);         /* surfels parked in submap caches */
+void ora_map_submap_origin(const ora_ctx* c, int32_t* ij);
+
+/* SurfelMapping::processScan (src/core/SurfelMapping.cpp:175-210) without loop closures */
+typedef struct ora_pipeline ora_pipeline;
+ora_pipeline* ora_pipeline_create(const suma_params* p);
+void ora_pipeline_destroy(ora_pipeline* s);
+ora_ctx* ora_pipeline_ctx(ora_pipeline* s);
+/* fixed_iterations > 0: run exactly that many GN iterations (bench mode) */
+void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations);
+void ora_pipeline_pose(const ora_pipeline* s, double pose[16]);
+void ora_pipeline_last_increment(const ora_pipeline* s, double inc[16]);
+void ora_pipeline_last_stats(const ora_pipeline* s, suma_icp_stats* st);
+ora_frame* ora_pipeline_frame(ora_pipeline* s, int which); /* 0 current data, 1 last model, 2 current model */
+
+/* host math exposed for tests: SE3::exp (lie_algebra.cpp:4-34), 6x6 LDLT solve */
+void ora_se3_exp(const double x[6], double T[16]);
+void ora_solve6(const double* JtJ, const double* Jtr, double* dx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
