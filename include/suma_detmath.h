@@ -106,13 +106,10 @@ SUMA_HD float sdm_atan2(float y, float x) {
   return z;
 }
 
-SUMA_HD float sdm_sqrt(float x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return __fsqrt_rn(x);
-#else
-  return __builtin_sqrtf(x);
-#endif
-}
+/* correctly rounded on both sides: hipcc lowers __builtin_sqrtf to the IEEE sequence under its default
+ * -fhip-fp32-correctly-rounded-divide-sqrt (HIP's __fsqrt_rn is NOT: it maps to the native
+ * approximation, measured 15 % 1-ulp mismatches on gfx950 -- tools/fpcheck.hip) */
+SUMA_HD float sdm_sqrt(float x) { return __builtin_sqrtf(x); }
 
 SUMA_HD float sdm_asin(float xx) {
   float a = sdm_abs(xx);
@@ -263,5 +260,61 @@ SUMA_HD float sdm_log(float xx) {
   z = z + 0.693359375f * fe;
   return z;
 }
+
+/* ---- double-precision sin / cos (SE3::exp of the Gauss-Newton update, reference
+ * src/core/lie_algebra.cpp:4-34, runs on the device in the gfx950 build and on the host in the
+ * oracle; both must produce the same pose bits).  Cephes double kernels restated; |x| <= 2^30;
+ * accuracy ~1 ulp (tests/test_detmath.py). */
+SUMA_HD double sdm_floor_d(double x) {
+  if (!((x < 0 ? -x : x) < 4503599627370496.0)) return x;
+  double t = (double)(int64_t)x;
+  return (t > x) ? (t - 1.0) : t;
+}
+SUMA_HD double sdm_sincos_core_d(double xx, int want_cos) {
+  const double DP1 = 7.85398125648498535156E-1, DP2 = 3.77489470793079817668E-8, DP3 = 2.69515142907905952645E-15;
+  const double FOPI = 1.27323954473516268615; /* 4/pi */
+  int sign = 1;
+  double x = xx;
+  if (x < 0.0) {
+    x = -x;
+    if (!want_cos) sign = -1;
+  }
+  if (!(x <= 1073741824.0)) return xx - xx; /* NaN for inf / NaN, 0 beyond the supported range */
+  double y = sdm_floor_d(x * FOPI);
+  int64_t j = (int64_t)y;
+  if (j & 1) {
+    j += 1;
+    y += 1.0;
+  }
+  j &= 7;
+  if (j > 3) {
+    sign = -sign;
+    j -= 4;
+  }
+  if (want_cos && j > 1) sign = -sign;
+  double z = ((x - y * DP1) - y * DP2) - y * DP3;
+  double zz = z * z;
+  int use_cos_poly = want_cos ? !(j == 1 || j == 2) : (j == 1 || j == 2);
+  double r;
+  if (use_cos_poly) {
+    double p = -1.13585365213876817300E-11 * zz + 2.08757008419747316778E-9;
+    p = p * zz - 2.75573141792967388112E-7;
+    p = p * zz + 2.48015872888517045348E-5;
+    p = p * zz - 1.38888888888730564116E-3;
+    p = p * zz + 4.16666666666665929218E-2;
+    r = (1.0 - 0.5 * zz) + (zz * zz) * p;
+  } else {
+    double p = 1.58962301576546568060E-10 * zz - 2.50507477628578072866E-8;
+    p = p * zz + 2.75573136213857245213E-6;
+    p = p * zz - 1.98412698295895385996E-4;
+    p = p * zz + 8.33333333332211858878E-3;
+    p = p * zz - 1.66666666666666307295E-1;
+    r = z + (z * zz) * p;
+  }
+  return (sign < 0) ? -r : r;
+}
+SUMA_HD double sdm_sin_d(double x) { return sdm_sincos_core_d(x, 0); }
+SUMA_HD double sdm_cos_d(double x) { return sdm_sincos_core_d(x, 1); }
+SUMA_HD double sdm_sqrt_d(double x) { return __builtin_sqrt(x); }
 
 #endif /* SUMA_DETMATH_H_ */

@@ -1,0 +1,160 @@
+/*
+ * suma_hip.h -- C-ABI of the MI355X (gfx950) projective-ICP + surfel-fusion core.
+ *
+ * This is the drop-in boundary for the hot path of SuMa++ (PRBonn/semantic_suma).  Every entry
+ * point below replaces one method of the reference's C++ classes in src/core (Preprocessing,
+ * Frame2Model/Objective + LieGaussNewton, SurfelMap, and the per-scan sequencing of
+ * SurfelMapping); the reference-side adapter that keeps those class signatures and calls these
+ * functions is shown in INTEGRATION.md and include/suma_adapter.hpp.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no exceptions cross the boundary.
+ *  - return value: 0 = SUMA_OK, negative = error (suma_last_error() gives the text).
+ *  - one suma_ctx = one HIP device + one HIP stream; calls on a ctx are serialised by the caller
+ *    (as in the reference, whose methods all run on the thread that owns the GL context);
+ *    different ctxs may be driven from different threads / processes (one per GPU).
+ *  - matrices are column-major 4x4 (Eigen::Matrix4f / Matrix4d default storage).
+ *  - host pointers unless the name says _device.
+ *  - there is NO CPU fallback: without a gfx950 device suma_ctx_create fails.
+ */
+#ifndef SUMA_HIP_H_
+#define SUMA_HIP_H_
+
+#include <stdint.h>
+
+#include "suma_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  SUMA_OK = 0,
+  SUMA_ERR_INVALID = -1,  /* bad argument */
+  SUMA_ERR_HIP = -2,      /* HIP runtime error (no device, launch failure, ...) */
+  SUMA_ERR_CAPACITY = -3, /* surfel / pose / cache capacity exceeded (reference: silent TF truncation,
+                             SurfelMap.cpp:726-727) */
+  SUMA_ERR_NOMEM = -4
+};
+
+typedef struct suma_ctx suma_ctx;
+typedef struct suma_frame suma_frame;       /* reference: class Frame, src/core/Frame.h:21-79 */
+typedef struct suma_pipeline suma_pipeline; /* reference: class SurfelMapping, src/core/SurfelMapping.h */
+
+const char* suma_version(void);
+/* last error text of this ctx (or of the failed create when ctx == NULL) */
+const char* suma_last_error(const suma_ctx* ctx);
+
+/* ---- context: constructors / setParameters of Preprocessing, Frame2Model, LieGaussNewton,
+ *      SurfelMap (Preprocessing.cpp:16-118, Frame2Model.cpp:14-110, LieGaussNewton.cpp:81-91,
+ *      SurfelMap.cpp:8-457).  Image sizes and capacities are fixed at creation (textures and
+ *      buffers are sized in the reference's constructors); all other keys may be re-sent. */
+int suma_ctx_create(const suma_params* params, int hip_device, suma_ctx** out);
+void suma_ctx_destroy(suma_ctx* ctx);
+int suma_set_params(suma_ctx* ctx, const suma_params* params);
+int suma_synchronize(suma_ctx* ctx);
+/* the hipStream_t all work of this ctx is enqueued on (for event timing by the caller) */
+void* suma_ctx_stream(suma_ctx* ctx);
+
+/* ---- frames: Frame::Frame / Frame::copy (Frame.h:26-61); which = SUMA_MAP_* */
+int suma_frame_create(suma_ctx* ctx, uint32_t width, uint32_t height, suma_frame** out);
+void suma_frame_destroy(suma_frame* f);
+int suma_frame_copy(suma_ctx* ctx, suma_frame* dst, const suma_frame* src);
+int suma_frame_download(suma_ctx* ctx, const suma_frame* f, int which, suma_float4* host);
+int suma_frame_upload(suma_ctx* ctx, suma_frame* f, int which, const suma_float4* host);
+uint32_t suma_frame_width(const suma_frame* f);
+uint32_t suma_frame_height(const suma_frame* f);
+/* device address of one map (HIP->GL interop / zero-copy consumers) */
+void* suma_frame_device_ptr(const suma_frame* f, int which);
+
+/* ---- Preprocessing::process (Preprocessing.h:55-56, Preprocessing.cpp:120-339): K1 z-buffered
+ *      spherical scatter, K2 cross-stencil normals + label erosion, K3 label flood fill.
+ *      points: n x (x,y,z,1) as rv::Point3f; labels / probs: n floats (may be NULL). */
+int suma_preprocess(suma_ctx* ctx, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                    uint32_t timestamp, suma_frame* out);
+/* same with the scan already resident in HBM */
+int suma_preprocess_device(suma_ctx* ctx, const suma_float4* d_points, const float* d_labels, const float* d_probs,
+                           uint32_t n, uint32_t timestamp, suma_frame* out);
+
+/* ---- Objective::setData (Objective.h:58, Frame2Model.cpp:117-123) */
+int suma_icp_set_data(suma_ctx* ctx, const suma_frame* current, const suma_frame* model);
+/* ---- Frame2Model::jacobianProducts (Frame2Model.h:50, Frame2Model.cpp:136-261): K6 at the given
+ *      pose.  JtJ 6x6 column-major, Jtr 6; acc (optional) = the raw 2^-28 fixed-point sums,
+ *      SUMA_ACC_WORDS int64.  Returns F in stats->error. */
+int suma_icp_jacobian_products(suma_ctx* ctx, const double pose[16], uint32_t iteration, double JtJ[36], double Jtr[6],
+                               int64_t* acc, suma_icp_stats* stats);
+/* ---- LieGaussNewton::minimize (LieGaussNewton.h:32, LieGaussNewton.cpp:13-79) with
+ *      Objective::increment / SE3::exp (Objective.h:45-48, lie_algebra.cpp:4-34): the whole
+ *      Gauss-Newton loop runs on the device (no per-iteration readback).
+ *      history (optional): history_cap x 16 doubles receive LieGaussNewton::history(); *n_hist = entries pushed. */
+int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], double* history, uint32_t history_cap,
+                      uint32_t* n_hist, suma_icp_stats* stats);
+/* n_hyp independent minimisations of the same frame pair from different T0 (the reference's
+ * loop-closure verification pattern, SurfelMapping.cpp:662-779; BASELINE config 3) in one batch. */
+int suma_icp_minimize_batch(suma_ctx* ctx, const double* T0s, uint32_t n_hyp, double* T_out, suma_icp_stats* stats);
+
+/* ---- SurfelMap (SurfelMap.h:36-78) */
+int suma_map_reset(suma_ctx* ctx);                                                  /* SurfelMap.cpp:473-482 */
+int suma_map_update(suma_ctx* ctx, const float pose[16], const suma_frame* frame); /* SurfelMap.cpp:492-584 */
+/* render(pose_old, pose_new, frame, ct), SurfelMap.cpp:847-1021; also fills the OLD / NEW frames */
+int suma_map_render(suma_ctx* ctx, const float pose_old[16], const float pose_new[16], float conf_threshold,
+                    suma_frame* out);
+int suma_map_render_active(suma_ctx* ctx, const float pose[16], float conf_threshold);   /* SurfelMap.cpp:1023-1069 */
+int suma_map_render_inactive(suma_ctx* ctx, const float pose[16], float conf_threshold); /* SurfelMap.cpp:1071-1114 */
+int suma_map_render_composed(suma_ctx* ctx, const float pose_old[16], const float pose_new[16],
+                             float conf_threshold);                                      /* SurfelMap.cpp:1116-1165 */
+/* oldMapFrame() / newMapFrame() / composedFrame(), SurfelMap.h:59-61; which = SUMA_FRAME_* */
+suma_frame* suma_map_frame(suma_ctx* ctx, int which);
+int suma_map_update_poses(suma_ctx* ctx, const float* poses16, uint32_t n); /* SurfelMap.cpp:485-490 */
+int suma_map_size(suma_ctx* ctx, uint32_t* n);                              /* SurfelMap::size() */
+int suma_map_timestamp(suma_ctx* ctx, uint32_t* t);
+/* getAllSurfels(), SurfelMap.cpp:1232-1237: copies min(size, cap) surfels; *n = size */
+int suma_map_download(suma_ctx* ctx, suma_surfel* host, uint32_t cap, uint32_t* n);
+/* checkpoint / resume: replace the active map */
+int suma_map_upload(suma_ctx* ctx, const suma_surfel* host, uint32_t n, uint32_t timestamp);
+/* intermediates of the last update, for stage-by-stage parity tests */
+int suma_map_download_index_map(suma_ctx* ctx, uint32_t* host);      /* P, surfel id + 1 (uint32, not float) */
+int suma_map_download_radius_conf(suma_ctx* ctx, suma_float4* host); /* P */
+int suma_map_download_integrated(suma_ctx* ctx, uint8_t* host);      /* P */
+int suma_map_counts(suma_ctx* ctx, uint32_t* n_updated, uint32_t* n_new, uint32_t* n_cached, int32_t origin_ij[2]);
+
+/* ---- SurfelMapping::processScan (SurfelMapping.h:47, SurfelMapping.cpp:175-210) without the
+ *      loop-closure / pose-graph part: initialize, preprocess, updatePose
+ *      (incl. the frame-to-frame fallback, :434-449), updateMap.
+ *      fixed_iterations > 0 runs exactly that many GN iterations (bench mode). */
+int suma_pipeline_create(const suma_params* params, int hip_device, suma_pipeline** out);
+void suma_pipeline_destroy(suma_pipeline* s);
+suma_ctx* suma_pipeline_ctx(suma_pipeline* s);
+int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations);
+int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                                      const float* d_probs, uint32_t n, int32_t fixed_iterations);
+int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
+int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
+int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);
+uint32_t suma_pipeline_timestamp(const suma_pipeline* s);
+/* which: 0 current data frame, 1 last model frame, 2 current model frame */
+suma_frame* suma_pipeline_frame(suma_pipeline* s, int which);
+
+/* ---- device scratch for callers that keep scans resident in HBM (bench, replay) */
+int suma_device_alloc(suma_ctx* ctx, uint64_t bytes, void** d_ptr);
+int suma_device_free(suma_ctx* ctx, void* d_ptr);
+int suma_device_upload(suma_ctx* ctx, void* d_dst, const void* host_src, uint64_t bytes);
+
+/* ---- per-kernel timing (rv::Stopwatch / SurfelMapping::Stats, SurfelMapping.cpp:183-207):
+ *      when enabled every kernel launch is bracketed by HIP events on the ctx stream.
+ *      suma_profile_get fills up to cap entries, returns the number of distinct kernels. */
+typedef struct suma_kernel_time {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+  double bytes; /* algorithmic bytes summed over the launches (SURVEY.md 8d formulas) */
+} suma_kernel_time;
+int suma_profile_enable(suma_ctx* ctx, int on);
+int suma_profile_reset(suma_ctx* ctx);
+int suma_profile_get(suma_ctx* ctx, suma_kernel_time* out, uint32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMA_HIP_H_ */

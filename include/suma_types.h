@@ -95,6 +95,9 @@ typedef struct suma_params {
   /* reference quirk B-1 (Preprocessing.cpp:142-145): point i receives labels[i+4], probs[i+5].
    * label_offset/prob_offset reproduce (4,5) or fix (0,0) it; reads past the end yield 0. */
   uint32_t label_offset, prob_offset;
+  /* capacity (in surfels) of the HBM arena that holds the parked submap tiles; the reference keeps
+   * them in host RAM (SurfelMap.h:186).  0 = 4 * max_surfels. */
+  uint32_t cache_surfels;
 } suma_params;
 
 /* Unpacked row 7 of the reference's 2x8 blend target (Frame2Model.cpp:222-227) */
@@ -167,6 +170,7 @@ static inline void suma_params_default(suma_params* p) {
   p->max_poses = 10000;
   p->label_offset = 4;
   p->prob_offset = 5;
+  p->cache_surfels = 0;
 }
 
 #ifdef __cplusplus

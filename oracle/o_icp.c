@@ -217,10 +217,10 @@ void ora_se3_exp(const double x[6], double T[16]) {
     for (int r = 0; r < 3; ++r)
       for (int cc = 0; cc < 3; ++cc)
         K2[3 * r + cc] = (K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc]) + K[3 * r + 2] * K[6 + cc];
-    double alpha = sin(theta) / theta;
-    double beta = (1 - cos(theta)) / (theta * theta);
-    double gamma = (1.0 - cos(theta)) / (theta * theta);
-    double delta = (theta - sin(theta)) / (theta * theta * theta);
+    double alpha = sdm_sin_d(theta) / theta;
+    double beta = (1 - sdm_cos_d(theta)) / (theta * theta);
+    double gamma = (1.0 - sdm_cos_d(theta)) / (theta * theta);
+    double delta = (theta - sdm_sin_d(theta)) / (theta * theta * theta);
     for (int r = 0; r < 3; ++r) {
       double t = 0.0;
       for (int cc = 0; cc < 3; ++cc) {

@@ -25,6 +25,8 @@
 #define sdm_sin sinf
 #define sdm_exp expf
 #define sdm_log logf
+#define sdm_sin_d sin
+#define sdm_cos_d cos
 #endif
 
 typedef struct {

@@ -1,0 +1,518 @@
+"""Host-side mirror of the reference's hot-path classes over the C-ABI (include/suma_hip.h).
+
+The classes keep the names, argument meaning and error behaviour of the reference interfaces they
+stand for (PRBonn/semantic_suma, src/core):
+
+    Frame            src/core/Frame.h:21-79
+    Preprocessing    src/core/Preprocessing.h:47-58          process(points, frame, labels, probs, timestamp)
+    Frame2Model      src/core/Frame2Model.h:28-73 / Objective.h:14-82
+    LieGaussNewton   src/core/LieGaussNewton.h:25-76         minimize(objective, T0), pose(), history()
+    SurfelMap        src/core/SurfelMap.h:36-78              update / render* / *MapFrame / updatePoses / size
+    SurfelMapping    src/core/SurfelMapping.h:47             processScan(scan)
+
+Everything here is plumbing: numpy arrays in, ctypes calls into ``libsuma_hip.so`` (hand-written
+gfx950 kernels), numpy arrays out.  There is no CPU fallback -- if the library is missing or no
+MI355X is visible the constructors raise (the reference throws ``std::runtime_error`` in the
+same situations, e.g. Frame2Model.cpp:132).  Matrices are exchanged as row-major numpy 4x4 and
+converted to the column-major layout of Eigen at the boundary.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .types import ACC_WORDS, SURFEL_DTYPE, IcpStats, SumaParams
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsuma_hip.so")
+_LIB = None
+
+
+class SumaError(RuntimeError):
+    """Raised for every negative return code of the C-ABI (the reference throws std::runtime_error)."""
+
+
+class KernelTime(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("bytes", C.c_double)]
+
+
+def lib():
+    """Load libsuma_hip.so (built in-tree by ``__graft_entry__.build()`` / ``make -C semantic_suma_amd/csrc``)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise SumaError(f"{LIB_PATH} not found: build it with `make -C semantic_suma_amd/csrc` "
+                        "(there is no CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
+    pp = C.POINTER(vp)
+    L.suma_version.restype = C.c_char_p
+    L.suma_last_error.restype = C.c_char_p
+    L.suma_last_error.argtypes = [vp]
+    L.suma_ctx_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
+    L.suma_ctx_destroy.argtypes = [vp]
+    L.suma_ctx_destroy.restype = None
+    L.suma_set_params.argtypes = [vp, C.POINTER(SumaParams)]
+    L.suma_synchronize.argtypes = [vp]
+    L.suma_ctx_stream.restype = vp
+    L.suma_ctx_stream.argtypes = [vp]
+    L.suma_frame_create.argtypes = [vp, u32, u32, pp]
+    L.suma_frame_destroy.argtypes = [vp]
+    L.suma_frame_destroy.restype = None
+    L.suma_frame_copy.argtypes = [vp, vp, vp]
+    L.suma_frame_download.argtypes = [vp, vp, C.c_int, vp]
+    L.suma_frame_upload.argtypes = [vp, vp, C.c_int, vp]
+    L.suma_frame_width.restype = u32
+    L.suma_frame_width.argtypes = [vp]
+    L.suma_frame_height.restype = u32
+    L.suma_frame_height.argtypes = [vp]
+    L.suma_frame_device_ptr.restype = vp
+    L.suma_frame_device_ptr.argtypes = [vp, C.c_int]
+    L.suma_preprocess.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.suma_preprocess_device.argtypes = [vp, vp, vp, vp, u32, u32, vp]
+    L.suma_icp_set_data.argtypes = [vp, vp, vp]
+    L.suma_icp_jacobian_products.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(IcpStats)]
+    L.suma_icp_minimize.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(IcpStats)]
+    L.suma_icp_minimize_batch.argtypes = [vp, vp, u32, vp, vp]
+    L.suma_map_reset.argtypes = [vp]
+    L.suma_map_update.argtypes = [vp, vp, vp]
+    L.suma_map_render.argtypes = [vp, vp, vp, f32, vp]
+    L.suma_map_render_active.argtypes = [vp, vp, f32]
+    L.suma_map_render_inactive.argtypes = [vp, vp, f32]
+    L.suma_map_render_composed.argtypes = [vp, vp, vp, f32]
+    L.suma_map_frame.restype = vp
+    L.suma_map_frame.argtypes = [vp, C.c_int]
+    L.suma_map_update_poses.argtypes = [vp, vp, u32]
+    L.suma_map_size.argtypes = [vp, C.POINTER(u32)]
+    L.suma_map_timestamp.argtypes = [vp, C.POINTER(u32)]
+    L.suma_map_download.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.suma_map_upload.argtypes = [vp, vp, u32, u32]
+    L.suma_map_download_index_map.argtypes = [vp, vp]
+    L.suma_map_download_radius_conf.argtypes = [vp, vp]
+    L.suma_map_download_integrated.argtypes = [vp, vp]
+    L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
+    L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
+    L.suma_pipeline_destroy.argtypes = [vp]
+    L.suma_pipeline_destroy.restype = None
+    L.suma_pipeline_ctx.restype = vp
+    L.suma_pipeline_ctx.argtypes = [vp]
+    L.suma_pipeline_process_scan.argtypes = [vp, vp, vp, vp, u32, i32]
+    L.suma_pipeline_process_scan_device.argtypes = [vp, vp, vp, vp, u32, i32]
+    L.suma_pipeline_pose.argtypes = [vp, vp]
+    L.suma_pipeline_last_increment.argtypes = [vp, vp]
+    L.suma_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
+    L.suma_pipeline_timestamp.restype = u32
+    L.suma_pipeline_timestamp.argtypes = [vp]
+    L.suma_pipeline_frame.restype = vp
+    L.suma_pipeline_frame.argtypes = [vp, C.c_int]
+    L.suma_device_alloc.argtypes = [vp, C.c_uint64, pp]
+    L.suma_device_free.argtypes = [vp, vp]
+    L.suma_device_upload.argtypes = [vp, vp, vp, C.c_uint64]
+    L.suma_profile_enable.argtypes = [vp, C.c_int]
+    L.suma_profile_reset.argtypes = [vp]
+    L.suma_profile_get.argtypes = [vp, C.POINTER(KernelTime), u32]
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _cm(T, dtype):
+    """row-major numpy 4x4 -> column-major (Eigen) buffer"""
+    return np.ascontiguousarray(np.asarray(T, dtype=dtype).reshape(4, 4).T)
+
+
+class Context:
+    """One HIP device + stream + all device-resident state of the hot path (suma_ctx)."""
+
+    def __init__(self, params: SumaParams, device: int = 0, handle=None, owner=None):
+        self.L = lib()
+        self.params = params
+        self._owner = owner
+        if handle is None:
+            h = C.c_void_p()
+            rc = self.L.suma_ctx_create(C.byref(params), device, C.byref(h))
+            if rc != 0:
+                raise SumaError(f"suma_ctx_create failed ({rc}): {self.L.suma_last_error(None).decode()}")
+            self.h, self.owned = h, True
+        else:
+            self.h, self.owned = handle, False
+
+    def check(self, rc: int, what: str = ""):
+        if rc != 0:
+            raise SumaError(f"{what} failed ({rc}): {self.L.suma_last_error(self.h).decode()}")
+
+    def set_params(self, params: SumaParams):
+        self.check(self.L.suma_set_params(self.h, C.byref(params)), "suma_set_params")
+        self.params = params
+
+    def synchronize(self):
+        self.check(self.L.suma_synchronize(self.h), "suma_synchronize")
+
+    @property
+    def stream(self) -> int:
+        return int(self.L.suma_ctx_stream(self.h) or 0)
+
+    # device scratch for resident scans
+    def device_array(self, host: np.ndarray) -> int:
+        host = np.ascontiguousarray(host)
+        p = C.c_void_p()
+        self.check(self.L.suma_device_alloc(self.h, host.nbytes, C.byref(p)), "suma_device_alloc")
+        self.check(self.L.suma_device_upload(self.h, p, _ptr(host), host.nbytes), "suma_device_upload")
+        return p.value
+
+    def device_free(self, p: int):
+        self.check(self.L.suma_device_free(self.h, C.c_void_p(p)), "suma_device_free")
+
+    # profiling
+    def profile(self, on: bool):
+        self.check(self.L.suma_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self.check(self.L.suma_profile_reset(self.h))
+
+    def profile_get(self):
+        buf = (KernelTime * 64)()
+        n = self.L.suma_profile_get(self.h, buf, 64)
+        if n < 0:
+            self.check(n, "suma_profile_get")
+        return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
+                     bytes=float(buf[i].bytes)) for i in range(min(n, 64))]
+
+    def close(self):
+        if getattr(self, "owned", False) and self.h:
+            self.L.suma_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Frame:
+    """Frame.h:21-79: vertex / normal / semantic maps (H x W x 4 float32, row 0 = lowest beam) in HBM."""
+
+    def __init__(self, ctx: Context, width: int, height: int, handle=None):
+        self.ctx, self.width, self.height = ctx, width, height
+        if handle is None:
+            h = C.c_void_p()
+            ctx.check(ctx.L.suma_frame_create(ctx.h, width, height, C.byref(h)), "suma_frame_create")
+            self.h, self.owned = h, True
+        else:
+            self.h, self.owned = C.c_void_p(handle), False
+
+    def download(self, which: int) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        self.ctx.check(self.ctx.L.suma_frame_download(self.ctx.h, self.h, which, _ptr(out)), "suma_frame_download")
+        return out
+
+    def upload(self, which: int, data: np.ndarray):
+        data = np.ascontiguousarray(data, dtype=np.float32).reshape(self.height, self.width, 4)
+        self.ctx.check(self.ctx.L.suma_frame_upload(self.ctx.h, self.h, which, _ptr(data)), "suma_frame_upload")
+
+    def set(self, vertex, normal, semantic):
+        self.upload(0, vertex)
+        self.upload(1, normal)
+        self.upload(2, semantic)
+
+    @property
+    def vertex(self):
+        return self.download(0)
+
+    @property
+    def normal(self):
+        return self.download(1)
+
+    @property
+    def semantic(self):
+        return self.download(2)
+
+    def copy(self, other: "Frame"):
+        """Frame::copy (Frame.h:49-61)"""
+        self.ctx.check(self.ctx.L.suma_frame_copy(self.ctx.h, self.h, other.h), "suma_frame_copy")
+
+    def __del__(self):
+        try:
+            if getattr(self, "owned", False) and self.h and self.ctx.h:
+                self.ctx.L.suma_frame_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class Preprocessing:
+    """Preprocessing.h:47-58"""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def process(self, points, frame: Frame, labels, probs, timestamp: int) -> Frame:
+        points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        probs = None if probs is None else np.ascontiguousarray(probs, dtype=np.float32)
+        c = self.ctx
+        c.check(c.L.suma_preprocess(c.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0], timestamp, frame.h),
+                "suma_preprocess")
+        return frame
+
+
+class Frame2Model:
+    """Objective.h:14-82 as implemented by Frame2Model.h:28-73."""
+    num_parameters = 6
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._pose = np.eye(4)
+        self._iteration = 0
+        self.stats = IcpStats()
+        self.acc = np.zeros(ACC_WORDS, dtype=np.int64)
+
+    def setData(self, current: Frame, last: Frame):
+        self._current, self._last = current, last  # keep alive
+        self.ctx.check(self.ctx.L.suma_icp_set_data(self.ctx.h, current.h, last.h), "suma_icp_set_data")
+        self._iteration = 0
+
+    def initialize(self, pose):
+        self._pose = np.asarray(pose, dtype=np.float64).copy()
+        self._iteration = 0
+
+    def pose(self):
+        return self._pose
+
+    def jacobianProducts(self):
+        """returns (F, JtJ[6,6], Jtf[6]); updates inlier()/outlier()/valid()/invalid()"""
+        JtJ = np.zeros((6, 6), dtype=np.float64)
+        Jtr = np.zeros(6, dtype=np.float64)
+        pose = _cm(self._pose, np.float64)
+        c = self.ctx
+        c.check(c.L.suma_icp_jacobian_products(c.h, _ptr(pose), self._iteration, _ptr(JtJ), _ptr(Jtr), _ptr(self.acc),
+                                               C.byref(self.stats)), "suma_icp_jacobian_products")
+        self._iteration += 1
+        return self.stats.error, JtJ.T.copy(), Jtr
+
+    def inlier(self):
+        return self.stats.inlier
+
+    def outlier(self):
+        return self.stats.outlier
+
+    def valid(self):
+        return self.stats.valid
+
+    def invalid(self):
+        return self.stats.invalid
+
+    def inlier_residual(self):
+        return self.stats.inlier_residual
+
+
+class LieGaussNewton:
+    """LieGaussNewton.h:25-76: the loop itself runs on the device (one readback per minimize)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._pose = np.eye(4)
+        self._history = np.zeros((0, 4, 4))
+        self.stats = IcpStats()
+
+    def minimize(self, objective: Frame2Model, T0, history_cap: int = 64) -> int:
+        T0 = _cm(T0, np.float64)
+        T = np.zeros((4, 4), dtype=np.float64)
+        hist = np.zeros((history_cap, 4, 4), dtype=np.float64)
+        nh = C.c_uint32(0)
+        c = self.ctx
+        c.check(c.L.suma_icp_minimize(c.h, _ptr(T0), _ptr(T), _ptr(hist) if history_cap else None, history_cap,
+                                      C.byref(nh), C.byref(self.stats)), "suma_icp_minimize")
+        self._pose = T.T.copy()
+        objective._pose = self._pose
+        objective.stats = self.stats
+        n = min(nh.value, history_cap)
+        self._history = hist[:n].transpose(0, 2, 1).copy()
+        return 0
+
+    def minimize_batch(self, T0s):
+        """n_hyp minimisations of the same frame pair (SurfelMapping.cpp:662-779 pattern)"""
+        T0s = np.ascontiguousarray(np.asarray(T0s, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
+        n = T0s.shape[0]
+        out = np.zeros((n, 4, 4), dtype=np.float64)
+        stats = (IcpStats * n)()
+        c = self.ctx
+        c.check(c.L.suma_icp_minimize_batch(c.h, _ptr(T0s), n, _ptr(out), stats), "suma_icp_minimize_batch")
+        return out.transpose(0, 2, 1).copy(), [stats[i].as_dict() for i in range(n)]
+
+    def pose(self):
+        return self._pose
+
+    def history(self):
+        return self._history
+
+    def iterationCount(self):
+        return self.stats.iterations
+
+
+class SurfelMap:
+    """SurfelMap.h:36-78"""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+
+    def reset(self):
+        self.ctx.check(self.ctx.L.suma_map_reset(self.ctx.h), "suma_map_reset")
+
+    def update(self, pose, frame: Frame):
+        p = _cm(pose, np.float32)
+        self.ctx.check(self.ctx.L.suma_map_update(self.ctx.h, _ptr(p), frame.h), "suma_map_update")
+
+    def render(self, pose_old, pose_new, frame: Frame, confidence_threshold: float):
+        po, pn = _cm(pose_old, np.float32), _cm(pose_new, np.float32)
+        self.ctx.check(self.ctx.L.suma_map_render(self.ctx.h, _ptr(po), _ptr(pn), confidence_threshold, frame.h),
+                       "suma_map_render")
+        return frame
+
+    def render_active(self, pose, confidence_threshold: float):
+        p = _cm(pose, np.float32)
+        self.ctx.check(self.ctx.L.suma_map_render_active(self.ctx.h, _ptr(p), confidence_threshold))
+
+    def render_inactive(self, pose, confidence_threshold: float):
+        p = _cm(pose, np.float32)
+        self.ctx.check(self.ctx.L.suma_map_render_inactive(self.ctx.h, _ptr(p), confidence_threshold))
+
+    def render_composed(self, pose_old, pose_new, confidence_threshold: float):
+        po, pn = _cm(pose_old, np.float32), _cm(pose_new, np.float32)
+        self.ctx.check(self.ctx.L.suma_map_render_composed(self.ctx.h, _ptr(po), _ptr(pn), confidence_threshold))
+
+    def _frame(self, which):
+        p = self.ctx.params
+        return Frame(self.ctx, p.model_width, p.model_height, handle=self.ctx.L.suma_map_frame(self.ctx.h, which))
+
+    def oldMapFrame(self):
+        return self._frame(0)
+
+    def newMapFrame(self):
+        return self._frame(1)
+
+    def composedFrame(self):
+        return self._frame(2)
+
+    def updatePoses(self, poses):
+        poses = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+        self.ctx.check(self.ctx.L.suma_map_update_poses(self.ctx.h, _ptr(poses), poses.shape[0]))
+
+    def size(self) -> int:
+        n = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_size(self.ctx.h, C.byref(n)), "suma_map_size")
+        return n.value
+
+    def timestamp(self) -> int:
+        t = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_timestamp(self.ctx.h, C.byref(t)))
+        return t.value
+
+    def getAllSurfels(self) -> np.ndarray:
+        n = self.size()
+        out = np.zeros(n, dtype=SURFEL_DTYPE)
+        got = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_download(self.ctx.h, _ptr(out) if n else None, n, C.byref(got)))
+        return out
+
+    def upload(self, surfels: np.ndarray, timestamp: int):
+        surfels = np.ascontiguousarray(surfels, dtype=SURFEL_DTYPE)
+        self.ctx.check(self.ctx.L.suma_map_upload(self.ctx.h, _ptr(surfels), surfels.shape[0], timestamp))
+
+    # intermediates of the last update (parity tests)
+    def index_map(self):
+        p = self.ctx.params
+        out = np.zeros((p.data_height, p.data_width), dtype=np.uint32)
+        self.ctx.check(self.ctx.L.suma_map_download_index_map(self.ctx.h, _ptr(out)))
+        return out
+
+    def radius_conf(self):
+        p = self.ctx.params
+        out = np.zeros((p.data_height, p.data_width, 4), dtype=np.float32)
+        self.ctx.check(self.ctx.L.suma_map_download_radius_conf(self.ctx.h, _ptr(out)))
+        return out
+
+    def integrated(self):
+        p = self.ctx.params
+        out = np.zeros((p.data_height, p.data_width), dtype=np.uint8)
+        self.ctx.check(self.ctx.L.suma_map_download_integrated(self.ctx.h, _ptr(out)))
+        return out
+
+    def counts(self):
+        """(S' survivors of K9, D new surfels of K10, surfels parked in submap caches, submap origin)"""
+        a, b, cc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        ij = np.zeros(2, dtype=np.int32)
+        self.ctx.check(self.ctx.L.suma_map_counts(self.ctx.h, C.byref(a), C.byref(b), C.byref(cc), _ptr(ij)))
+        return a.value, b.value, cc.value, (int(ij[0]), int(ij[1]))
+
+
+class SurfelMapping:
+    """SurfelMapping::processScan (SurfelMapping.cpp:175-210) without loop closures / pose graph."""
+
+    def __init__(self, params: SumaParams, device: int = 0):
+        self.L = lib()
+        self.params = params
+        h = C.c_void_p()
+        rc = self.L.suma_pipeline_create(C.byref(params), device, C.byref(h))
+        if rc != 0:
+            raise SumaError(f"suma_pipeline_create failed ({rc}): {self.L.suma_last_error(None).decode()}")
+        self.h = h
+        self.ctx = Context(params, handle=C.c_void_p(self.L.suma_pipeline_ctx(h)), owner=self)
+        self.map = SurfelMap(self.ctx)
+
+    def processScan(self, points, labels=None, probs=None, fixed_iterations: int = 0):
+        points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        probs = None if probs is None else np.ascontiguousarray(probs, dtype=np.float32)
+        self.ctx.check(self.L.suma_pipeline_process_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs),
+                                                         points.shape[0], fixed_iterations),
+                       "suma_pipeline_process_scan")
+
+    def processScanDevice(self, d_points: int, d_labels: int, d_probs: int, n: int, fixed_iterations: int = 0):
+        """scan already resident in HBM (device addresses from Context.device_array)"""
+        self.ctx.check(self.L.suma_pipeline_process_scan_device(self.h, C.c_void_p(d_points), C.c_void_p(d_labels),
+                                                                C.c_void_p(d_probs), n, fixed_iterations),
+                       "suma_pipeline_process_scan_device")
+
+    def getCurrentPose(self):
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.L.suma_pipeline_pose(self.h, _ptr(T))
+        return T.T.copy()
+
+    def lastIncrement(self):
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.L.suma_pipeline_last_increment(self.h, _ptr(T))
+        return T.T.copy()
+
+    def lastStats(self) -> IcpStats:
+        st = IcpStats()
+        self.L.suma_pipeline_last_stats(self.h, C.byref(st))
+        return st
+
+    def timestamp(self) -> int:
+        return self.L.suma_pipeline_timestamp(self.h)
+
+    def frame(self, which: int) -> Frame:
+        """0 current data frame, 1 last model frame, 2 current model frame"""
+        p = self.params
+        w, h = (p.data_width, p.data_height) if which == 0 else (p.model_width, p.model_height)
+        return Frame(self.ctx, w, h, handle=self.L.suma_pipeline_frame(self.h, which))
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.suma_pipeline_destroy(self.h)
+            self.h = None
+            self.ctx.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

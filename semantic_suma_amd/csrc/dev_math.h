@@ -1,0 +1,130 @@
+/*
+ * dev_math.h -- fp32 vector / matrix helpers of the gfx950 kernels.
+ *
+ * The projective pipeline turns floats into pixel indices through floor(), so the ORDER of the
+ * fp32 operations is part of the specification (DESIGN.md "Determinism"): every expression below
+ * is written as an explicit sequence of IEEE binary32 +,-,*,/,sqrt with the association the
+ * reference's GLSL built-ins imply (dot, cross, length, normalize, mat4*vec4, mat4*mat4;
+ * e.g. src/shader/gen_vertexmap.vert:73-103).  All translation units are compiled with
+ * -ffp-contract=off so no FMA is formed; hipcc's fp32 divide / sqrt are correctly rounded.
+ * Transcendentals come from include/suma_detmath.h.
+ */
+#ifndef SUMA_DEV_MATH_H_
+#define SUMA_DEV_MATH_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/suma_detmath.h"
+#include "../../include/suma_types.h"
+
+#define SDEV __device__ __forceinline__
+
+struct v3 {
+  float x, y, z;
+};
+
+SDEV v3 mk3(float x, float y, float z) {
+  v3 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  return r;
+}
+SDEV v3 xyz(const float4& a) { return mk3(a.x, a.y, a.z); }
+SDEV float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+SDEV float len3(v3 a) { return sdm_sqrt(dot3(a, a)); }
+SDEV v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SDEV v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SDEV v3 scale3(float s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+SDEV v3 divs3(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+SDEV v3 neg3(v3 a) { return mk3(-a.x, -a.y, -a.z); }
+SDEV v3 normalize3(v3 a) { return divs3(a, len3(a)); } /* GLSL normalize(): v / length(v) */
+SDEV v3 cross3(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+
+/* column-major 4x4 by value (kernel argument / register resident) */
+struct m4 {
+  float m[16];
+};
+
+/* M * (p, 1): ((col0*x + col1*y) + col2*z) + col3 */
+SDEV v3 m4_point(const float* m, v3 p) {
+  v3 r;
+  r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12];
+  r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13];
+  r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14];
+  return r;
+}
+/* M * (d, 0) */
+SDEV v3 m4_dir(const float* m, v3 d) {
+  v3 r;
+  r.x = (m[0] * d.x + m[4] * d.y) + m[8] * d.z;
+  r.y = (m[1] * d.x + m[5] * d.y) + m[9] * d.z;
+  r.z = (m[2] * d.x + m[6] * d.y) + m[10] * d.z;
+  return r;
+}
+/* upper 3x4 of C = A * B for rigid A, B (bottom row 0,0,0,1 is implied and exact):
+ * each element ((a0*b0 + a1*b1) + a2*b2) + a3*b3 with b3 in {0, 1} */
+SDEV void m4_mul(const float* A, const float* B, float* C) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      C[4 * c + r] =
+          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+  }
+}
+
+SDEV float fclamp(float x, float lo, float hi) {
+  float t = (x < lo) ? lo : x;
+  return (t > hi) ? hi : t;
+}
+SDEV float fmin_(float a, float b) { return (b < a) ? b : a; }
+SDEV float fmax_(float a, float b) { return (a < b) ? b : a; }
+
+/* color.glsl:31-37 pack() */
+SDEV float pack_rgb(float r, float g, float b) {
+  int32_t rgb = (int32_t)sdm_round(r * 255.0f);
+  rgb = (rgb << 8) + (int32_t)sdm_round(g * 255.0f);
+  rgb = (rgb << 8) + (int32_t)sdm_round(b * 255.0f);
+  return (float)rgb;
+}
+
+/* color_map.glsl:8-17: car, bicycle, bus, motorcycle, truck, other-vehicle, person, bicyclist,
+ * motorcyclist -- the classes the shaders treat as movable */
+SDEV bool is_dynamic_label(float l) {
+  return l == 10.0f || l == 11.0f || l == 13.0f || l == 15.0f || l == 18.0f || l == 20.0f || l == 30.0f ||
+         l == 31.0f || l == 32.0f;
+}
+
+/* 24-bit unorm depth (GL_DEPTH24_STENCIL8 renderbuffers of the reference) */
+SDEV uint32_t depth24(float zw) { return (uint32_t)(zw * 16777215.0f + 0.5f); }
+
+/* spherical projection parameters of one image (data or model) */
+struct proj_t {
+  float fov_up, fov, min_depth, max_depth, width, height;
+  int32_t W, H;
+};
+
+/* the projection repeated in five shaders (gen_indexmap.vert:37-52 et al.): (x01, y01, z01) */
+SDEV v3 project01(const proj_t& q, v3 p) {
+  float depth = len3(p);
+  float yaw = sdm_atan2(p.y, p.x);
+  float pitch = -sdm_asin(p.z / depth);
+  v3 r;
+  r.x = 0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f);
+  r.y = 1.0f - ((pitch * SUMA_RAD2DEG_F) + q.fov_up) / q.fov;
+  r.z = (depth - q.min_depth) / (q.max_depth - q.min_depth);
+  return r;
+}
+
+SDEV float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
+/* NEAREST + CLAMP_TO_BORDER texel fetch (border colour 0) */
+SDEV float4 texel(const float4* __restrict__ map, int32_t w, int32_t h, int32_t x, int32_t y) {
+  if (x < 0 || y < 0 || x >= w || y >= h) return f4(0.f, 0.f, 0.f, 0.f);
+  return map[(size_t)y * (size_t)w + (size_t)x];
+}
+
+#define SUMA_EMPTY_KEY (~0ull)
+
+#endif

@@ -1,0 +1,465 @@
+/*
+ * k_icp.hip -- K6 + the Gauss-Newton loop, device resident.
+ *
+ * Replaces (reference):
+ *   Frame2Model::jacobianProducts   src/core/Frame2Model.cpp:136-261
+ *     + src/shader/Frame2Model_jacobians.geom:53-247 (association, gating, Huber/Tukey and
+ *       semantic weights, J^T W J / J^T W r / statistics)
+ *   LieGaussNewton::minimize / step src/core/LieGaussNewton.cpp:13-79
+ *   Objective::increment            src/core/Objective.h:45-48
+ *   SE3::exp                        src/core/lie_algebra.cpp:4-34
+ *
+ * GL structure replaced: the reference draws ceil(W/64)*H geometry-shader threads that each
+ * loop over 64 pixels and blend-add 16 RGB32F points into a 2x8 target (undefined summation
+ * order), then glFinish + 192-byte readback + host LDLT per iteration.  Here:
+ *   - one lane per data pixel (grid-stride), 3 coalesced float4 loads of the data maps, 12
+ *     float4 bilinear taps of the model maps (L2 resident: 6 maps = 12.6 MB at 64x2048);
+ *   - every fp32 term is converted to 2^-28 fixed point (round to nearest even, via the
+ *     1.5*2^52 double trick) and summed as int64: exact and order independent, so the result is
+ *     bit-identical for any reduction tree (and to the CPU oracle);
+ *   - per-lane int64 accumulators -> wave butterfly (halving exchange, 32 shuffles of 64 bit)
+ *     -> LDS across the 4 waves -> one 256-byte partial per block, written write-through;
+ *   - the last block to arrive (ticket) sums the partials, solves the 6x6 system by LDL^T in
+ *     fp64, applies exp(delta) to the pose and evaluates the stopping tests, all in HBM-resident
+ *     state: the next iteration is just the next launch, there is no host round trip.
+ */
+#include "suma_internal.h"
+
+#define ICP_THREADS 256
+#define MAGIC_D 6755399441055744.0          /* 1.5 * 2^52 */
+#define MAGIC_BITS 0x4338000000000000ll     /* its bit pattern */
+
+struct IcpArgs {
+  const float4 *Vd, *Nd, *Sd; /* data frame, exact texels */
+  const float4 *Vm, *Nm, *Sm; /* model frame, bilinear / nearest */
+  int32_t W, H, Wm, Hm;
+  float fov_up, fov; /* of the data image (Frame2Model.cpp:82-99) */
+  float angle_thresh, distance_thresh, factor;
+  int32_t weight_function, bilinear;
+  uint32_t P;
+};
+
+__device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map, int32_t w, int32_t h, float x,
+                                                 float y) {
+  /* GL_LINEAR + CLAMP_TO_BORDER on a rectangle texture (GL 3.3 spec 3.8.11): texel centres at
+   * integer + 0.5, border (0,0,0,0); all four channels filtered (quirk B-5) */
+  float u = x - 0.5f, v = y - 0.5f;
+  float fu = sdm_floor(u), fv = sdm_floor(v);
+  float a = u - fu, b = v - fv;
+  int32_t i0 = (int32_t)fu, j0 = (int32_t)fv;
+  float4 t00 = texel(map, w, h, i0, j0);
+  float4 t10 = texel(map, w, h, i0 + 1, j0);
+  float4 t01 = texel(map, w, h, i0, j0 + 1);
+  float4 t11 = texel(map, w, h, i0 + 1, j0 + 1);
+  float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  float4 r;
+  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  return r;
+}
+
+/* raw magic-number bits of round(term * 2^28); MAGIC_BITS is subtracted once per term after the
+ * reduction (count * MAGIC_BITS, modulo 2^64) */
+__device__ __forceinline__ long long fix_bits(float term) {
+  double d = (double)term * SUMA_ACC_SCALE + MAGIC_D;
+  return __double_as_longlong(d);
+}
+
+__device__ __forceinline__ long long shfl_xor_ll(long long v, int mask) {
+  int lo = __shfl_xor((int)(v & 0xffffffffll), mask, 64);
+  int hi = __shfl_xor((int)(v >> 32), mask, 64);
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+/* Butterfly reduction of 32 per-lane words over a 64-lane wave: at each stage a lane keeps half
+ * of its words and trades the other half with its partner, so 32 -> 1 word per lane costs
+ * 16+8+4+2+1 exchanges plus one final pairwise add.  Afterwards lane L holds the wave total of
+ * word ((L>>5)&1)*16 + ((L>>4)&1)*8 + ((L>>3)&1)*4 + ((L>>2)&1)*2 + ((L>>1)&1). */
+__device__ __forceinline__ long long wave_reduce32(long long (&a)[SUMA_ACC_WORDS], int lane) {
+#pragma unroll
+  for (int h = 16, mask = 32; h >= 1; h >>= 1, mask >>= 1) {
+    const bool upper = (lane & mask) != 0;
+#pragma unroll
+    for (int i = 0; i < h; ++i) {
+      long long keep = upper ? a[i + h] : a[i];
+      long long send = upper ? a[i] : a[i + h];
+      a[i] = keep + shfl_xor_ll(send, mask);
+    }
+  }
+  return a[0] + shfl_xor_ll(a[0], 1);
+}
+__device__ __forceinline__ int word_of_lane(int lane) {
+  return ((lane >> 5) & 1) * 16 + ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 +
+         ((lane >> 1) & 1);
+}
+
+/* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64, fixed operation order */
+__device__ void solve6(const double* A, const double* b, double* x) {
+  double L[36], D[6], y[6];
+  for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  for (int j = 0; j < 6; ++j) {
+    double d = A[6 * j + j];
+    for (int k = 0; k < j; ++k) d -= (L[6 * k + j] * L[6 * k + j]) * D[k];
+    D[j] = d;
+    L[6 * j + j] = 1.0;
+    for (int i = j + 1; i < 6; ++i) {
+      double s = A[6 * j + i];
+      for (int k = 0; k < j; ++k) s -= (L[6 * k + i] * L[6 * k + j]) * D[k];
+      L[6 * j + i] = s / d;
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    double s = -b[i];
+    for (int k = 0; k < i; ++k) s -= L[6 * k + i] * y[k];
+    y[i] = s;
+  }
+  for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int k = i + 1; k < 6; ++k) s -= L[6 * i + k] * x[k];
+    x[i] = s;
+  }
+}
+
+/* SE3::exp, lie_algebra.cpp:4-34; x = (v, omega); column-major */
+__device__ void se3_exp(const double* x, double* T) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const double v[3] = {x[0], x[1], x[2]}, o[3] = {x[3], x[4], x[5]};
+  double theta = sdm_sqrt_d((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
+  if (theta > 1e-10) {
+    double K[9] = {0, -o[2], o[1], o[2], 0, -o[0], -o[1], o[0], 0};
+    double K2[9];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc)
+        K2[3 * r + cc] = (K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc]) + K[3 * r + 2] * K[6 + cc];
+    double alpha = sdm_sin_d(theta) / theta;
+    double beta = (1 - sdm_cos_d(theta)) / (theta * theta);
+    double gamma = (1.0 - sdm_cos_d(theta)) / (theta * theta);
+    double delta = (theta - sdm_sin_d(theta)) / (theta * theta * theta);
+    for (int r = 0; r < 3; ++r) {
+      double t = 0.0;
+      for (int cc = 0; cc < 3; ++cc) {
+        double I = (r == cc) ? 1.0 : 0.0;
+        T[4 * cc + r] = (I + alpha * K[3 * r + cc]) + beta * K2[3 * r + cc];
+        double Vrc = (I + gamma * K[3 * r + cc]) + delta * K2[3 * r + cc];
+        t += Vrc * v[cc];
+      }
+      T[12 + r] = t;
+    }
+  } else {
+    T[12] = v[0];
+    T[13] = v[1];
+    T[14] = v[2];
+  }
+}
+
+__device__ void mul4d(const double* A, const double* B, double* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      C[4 * c + r] =
+          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+}
+
+struct PoseD {
+  double m[16];
+};
+
+__device__ __forceinline__ void gn_reset(GnState* g, int t, uint32_t iteration0) {
+  if (t < SUMA_ACC_WORDS) g->acc[t] = 0;
+  if (t == 0) {
+    g->last_error = (double)3.402823466e+38f; /* LieGaussNewton.cpp:48 */
+    g->F = g->F_inlier = 0.0;
+    g->iteration = iteration0; /* Frame2Model::setData / initialize resets it to 0, Frame2Model.cpp:122 */
+    g->k = 0;
+    g->done = 0;
+    g->converged = 0;
+    g->valid = g->outlier = g->invalid = 0;
+    g->n_hist = 1;
+    g->ticket = 0;
+  }
+}
+
+/* LieGaussNewton::initialize (LieGaussNewton.cpp:36-51): one block per hypothesis */
+__global__ void k_gn_init(GnState* gn, const double* T0s, double* history, uint32_t iteration0) {
+  GnState* g = gn + blockIdx.x;
+  int t = threadIdx.x;
+  if (t < 16) {
+    g->Tk[t] = T0s[16 * blockIdx.x + t];
+    if (history != nullptr && blockIdx.x == 0) history[t] = T0s[t];
+  }
+  gn_reset(g, t, iteration0);
+}
+/* single hypothesis, T0 by value (no staging copy on the per-scan path) */
+__global__ void k_gn_init1(GnState* g, PoseD T0, double* history, uint32_t iteration0) {
+  int t = threadIdx.x;
+  if (t < 16) {
+    g->Tk[t] = T0.m[t];
+    if (history != nullptr) history[t] = T0.m[t];
+  }
+  gn_reset(g, t, iteration0);
+}
+
+/* One Gauss-Newton iteration (eval_only = 0) or one Frame2Model::jacobianProducts call at the
+ * pose / iteration stored in the state (eval_only = 1).  grid = (blocks, n_hyp). */
+__global__ void __launch_bounds__(ICP_THREADS)
+    k_icp_step(IcpArgs a, GnState* __restrict__ gn_all, long long* __restrict__ partial_all, uint32_t max_iter,
+               double epsilon, double delta_thr, int eval_only, double* __restrict__ history, uint32_t history_cap) {
+  GnState* gn = gn_all + blockIdx.y;
+  if (!eval_only && gn->done) return; /* converged / finished earlier: this launch is a no-op */
+  long long* partial = partial_all + (size_t)blockIdx.y * gridDim.x * SUMA_ACC_WORDS;
+
+  float T[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) T[i] = (float)gn->Tk[i]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
+  const uint32_t iteration = gn->iteration;
+
+  long long acc[SUMA_ACC_WORDS];
+#pragma unroll
+  for (int i = 0; i < SUMA_ACC_WORDS; ++i) acc[i] = 0;
+
+  const float fWm = (float)a.Wm, fHm = (float)a.Hm;
+  for (uint32_t pix = blockIdx.x * ICP_THREADS + threadIdx.x; pix < a.P; pix += gridDim.x * ICP_THREADS) {
+    float4 vd4 = a.Vd[pix], nd4 = a.Nd[pix];
+    float e_d = vd4.w + nd4.w;
+    bool pair = false;
+    float4 vm4, nm4, sm4;
+    v3 v_d, n_d;
+    if (e_d > 1.5f) {
+      v_d = m4_point(T, xyz(vd4));
+      n_d = m4_dir(T, xyz(nd4));
+      /* project2model, Frame2Model_jacobians.geom:53-65 */
+      float depth = len3(v_d);
+      float yaw = sdm_atan2(v_d.y, v_d.x);
+      float pitch = -sdm_asin(v_d.z / depth);
+      float ix = (0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f)) * fWm;
+      float iy = (1.0f - ((pitch * SUMA_RAD2DEG_F) + a.fov_up) / a.fov) * fHm;
+      bool in_image = (ix >= 0.0f && ix < fWm && iy >= 0.0f && iy < fHm); /* false for NaN */
+      if (in_image) {
+        if (a.bilinear) {
+          vm4 = bilinear_fetch(a.Vm, a.Wm, a.Hm, ix, iy);
+          nm4 = bilinear_fetch(a.Nm, a.Wm, a.Hm, ix, iy);
+        } else {
+          int32_t tx = (int32_t)sdm_floor(ix), ty = (int32_t)sdm_floor(iy);
+          vm4 = texel(a.Vm, a.Wm, a.Hm, tx, ty);
+          nm4 = texel(a.Nm, a.Wm, a.Hm, tx, ty);
+        }
+        float e_m = vm4.w + nm4.w;
+        if (e_m > 1.5f) {
+          pair = true;
+          if (a.bilinear)
+            sm4 = bilinear_fetch(a.Sm, a.Wm, a.Hm, ix, iy);
+          else
+            sm4 = texel(a.Sm, a.Wm, a.Hm, (int32_t)sdm_floor(ix), (int32_t)sdm_floor(iy));
+        }
+      }
+    }
+    if (pair) {
+      v3 v_m = xyz(vm4), n_m = xyz(nm4);
+      bool inlier = true;
+      if (len3(sub3(v_m, v_d)) > a.distance_thresh) inlier = false;
+      if (dot3(n_m, n_d) < a.angle_thresh) inlier = false;
+      float residual = dot3(n_m, sub3(v_d, v_m));
+      v3 cp = cross3(v_d, n_m);
+      float weight = 1.0f;
+      if (a.weight_function == 4 || a.weight_function == 1) { /* Huber, .geom:120-128 */
+        if (sdm_abs(residual) > a.factor) weight = a.factor / sdm_abs(residual);
+      } else if (a.weight_function == 2 && iteration > 0) { /* Tukey, .geom:129-141 */
+        if (sdm_abs(residual) > a.factor) {
+          weight = 0.0f;
+        } else {
+          float alpha = residual / a.factor;
+          weight = (1.0f - alpha * alpha);
+          weight = weight * weight;
+        }
+      }
+      /* semantic weighting, .geom:143-158 */
+      float4 sd4 = a.Sd[pix];
+      float data_label = sd4.x * 255.0f, data_prob = sd4.w;
+      float model_label = sm4.x * 255.0f;
+      if (is_dynamic_label(model_label)) {
+        if (sdm_round(data_label) != sdm_round(model_label))
+          weight *= (1.0f - data_prob);
+        else
+          weight *= data_prob;
+      }
+      float wr2 = (weight * residual) * residual;
+      acc[27] += fix_bits(wr2);
+      acc[29] += 1;
+      if (inlier) {
+        const float J[6] = {n_m.x, n_m.y, n_m.z, cp.x, cp.y, cp.z};
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          float wJi = weight * J[i];
+#pragma unroll
+          for (int j = i; j < 6; ++j) acc[k++] += fix_bits(wJi * J[j]);
+        }
+        float wr = weight * residual;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc[21 + i] += fix_bits(wr * J[i]);
+        acc[28] += fix_bits(wr2);
+      } else {
+        acc[30] += 1;
+      }
+    } else {
+      acc[31] += 1;
+    }
+  }
+
+  /* wave butterfly -> LDS -> block partial */
+  __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
+  __shared__ long long s_tot[8][SUMA_ACC_WORDS];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long tot = wave_reduce32(acc, lane);
+  if ((lane & 1) == 0) s_wave[wave][word_of_lane(lane)] = tot;
+  __syncthreads();
+  if (threadIdx.x < SUMA_ACC_WORDS) {
+    long long s = 0;
+#pragma unroll
+    for (int w = 0; w < ICP_THREADS / 64; ++w) s += s_wave[w][threadIdx.x];
+    /* write-through (agent-scope) store: visible to the last block without an L2 write-back */
+    __hip_atomic_store(&partial[(size_t)blockIdx.x * SUMA_ACC_WORDS + threadIdx.x], s, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t t = __hip_atomic_fetch_add(&gn->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+
+  /* ---- last block: total, solve, pose update ---- */
+  {
+    const int word = threadIdx.x & 31, grp = threadIdx.x >> 5; /* 8 groups of 32 words */
+    long long s = 0;
+    for (uint32_t b = grp; b < gridDim.x; b += 8)
+      s += __hip_atomic_load(&partial[(size_t)b * SUMA_ACC_WORDS + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_tot[grp][word] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+
+  long long tot_acc[SUMA_ACC_WORDS];
+  for (int w = 0; w < SUMA_ACC_WORDS; ++w) {
+    long long s = 0;
+    for (int g = 0; g < 8; ++g) s += s_tot[g][w];
+    tot_acc[w] = s;
+  }
+  const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
+  for (int w = 0; w < 27; ++w) tot_acc[w] -= n_inlier * MAGIC_BITS;
+  tot_acc[27] -= n_valid * MAGIC_BITS;
+  tot_acc[28] -= n_inlier * MAGIC_BITS;
+
+  const double inv = 1.0 / SUMA_ACC_SCALE;
+  double JtJ[36], Jtr[6];
+  {
+    int k = 0;
+    for (int i = 0; i < 6; ++i)
+      for (int j = i; j < 6; ++j) {
+        double v = (double)tot_acc[k++] * inv;
+        JtJ[6 * j + i] = v;
+        JtJ[6 * i + j] = v;
+      }
+    for (int i = 0; i < 6; ++i) Jtr[i] = (double)tot_acc[21 + i] * inv;
+  }
+  const double err = (double)tot_acc[27] * inv;
+  for (int w = 0; w < SUMA_ACC_WORDS; ++w) gn->acc[w] = tot_acc[w];
+  for (int i = 0; i < 36; ++i) gn->JtJ[i] = JtJ[i];
+  for (int i = 0; i < 6; ++i) gn->Jtr[i] = Jtr[i];
+  gn->F = err;
+  gn->F_inlier = (double)tot_acc[28] * inv;
+  gn->valid = (uint32_t)n_valid;
+  gn->outlier = (uint32_t)n_outlier;
+  gn->invalid = (uint32_t)tot_acc[31];
+  gn->ticket = 0; /* re-armed for the next launch (kernel boundary orders it) */
+  if (eval_only) return;
+
+  double dx[6];
+  solve6(JtJ, Jtr, dx);
+  int result = 1;
+  double linf = 0.0, maxc = Jtr[0];
+  for (int i = 0; i < 6; ++i) {
+    double ad = dx[i] < 0 ? -dx[i] : dx[i];
+    if (ad > linf) linf = ad;
+    if (Jtr[i] > maxc) maxc = Jtr[i];
+  }
+  const double last_error = gn->last_error;
+  if (linf < delta_thr) result = 0;                                                   /* LieGaussNewton.cpp:64 */
+  if ((maxc < 0 ? -maxc : maxc) < epsilon) result = 0;                                /* :65 (quirk B-4) */
+  double de = err - last_error;
+  if (err < last_error && (de < 0 ? -de : de) < epsilon) result = 0;                  /* :66 */
+  double E[16], Tk[16], Tn[16];
+  for (int i = 0; i < 16; ++i) Tk[i] = gn->Tk[i];
+  se3_exp(dx, E);
+  mul4d(E, Tk, Tn); /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
+  for (int i = 0; i < 16; ++i) gn->Tk[i] = Tn[i];
+  gn->iteration = iteration + 1;
+  gn->last_error = err;
+  if (result == 0) {
+    gn->converged = 1;
+    gn->done = 1;
+  } else {
+    uint32_t k = gn->k + 1;
+    gn->k = k;
+    uint32_t nh = gn->n_hist;
+    if (history != nullptr && blockIdx.y == 0 && nh < history_cap)
+      for (int i = 0; i < 16; ++i) history[16 * (size_t)nh + i] = Tn[i];
+    gn->n_hist = nh + 1;
+    if (k >= max_iter) gn->done = 1;
+  }
+}
+
+static IcpArgs make_args(suma_ctx* c) {
+  IcpArgs a;
+  const suma_frame *cur = c->icp_current, *mod = c->icp_model;
+  a.Vd = cur->map[SUMA_MAP_VERTEX];
+  a.Nd = cur->map[SUMA_MAP_NORMAL];
+  a.Sd = cur->map[SUMA_MAP_SEMANTIC];
+  a.Vm = mod->map[SUMA_MAP_VERTEX];
+  a.Nm = mod->map[SUMA_MAP_NORMAL];
+  a.Sm = mod->map[SUMA_MAP_SEMANTIC];
+  a.W = (int32_t)cur->width;
+  a.H = (int32_t)cur->height;
+  a.Wm = (int32_t)mod->width;
+  a.Hm = (int32_t)mod->height;
+  a.fov_up = c->pd.fov_up;
+  a.fov = c->pd.fov;
+  /* Frame2Model.cpp:66-67 */
+  a.angle_thresh = (float)cos((double)c->p.icp_max_angle * M_PI / 180.0);
+  a.distance_thresh = c->p.icp_max_distance;
+  a.factor = c->p.factor;
+  a.weight_function = c->p.weight_function;
+  a.bilinear = c->p.bilinear_sampling;
+  a.P = (uint32_t)a.W * (uint32_t)a.H;
+  return a;
+}
+
+hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0) {
+  double* hist = with_history ? c->gn_history : nullptr;
+  if (n_hyp == 1) {
+    PoseD T0;
+    for (int i = 0; i < 16; ++i) T0.m[i] = h_T0s[i];
+    k_gn_init1<<<1, 64, 0, c->stream>>>(c->gn, T0, hist, iteration0);
+  } else {
+    hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    if (e != hipSuccess) return e;
+    k_gn_init<<<n_hyp, 64, 0, c->stream>>>(c->gn, c->gn_T0s, hist, iteration0);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
+                                int eval_only, int with_history) {
+  IcpArgs a = make_args(c);
+  ProfScope ps(c, eval_only ? "k6_icp_eval" : "k6_icp_step", 96.0 * a.P * n_hyp);
+  dim3 grid(c->icp_blocks, n_hyp);
+  k_icp_step<<<grid, ICP_THREADS, 0, c->stream>>>(a, c->gn, (long long*)c->gn_partial, max_iter, epsilon, delta,
+                                                   eval_only, with_history ? c->gn_history : nullptr,
+                                                   c->gn_history_cap);
+  return hipGetLastError();
+}

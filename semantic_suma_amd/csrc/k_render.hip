@@ -1,0 +1,448 @@
+/*
+ * k_render.hip -- K4 + K5: surfel-map rendering on gfx950 (a compute rasteriser).
+ *
+ * Replaces (reference):
+ *   SurfelMap::render / render_active / render_inactive / render_composed
+ *       src/core/SurfelMap.cpp:847-1165
+ *   src/shader/render_surfels.vert:42-54  (surfel -> sensor frame via the creation pose)
+ *   src/shader/render_surfels.geom:76-123 (visibility / stability / age gating, 4-corner quad)
+ *   src/shader/render_surfels.frag:19-33  (unit-disc test, flat outputs)
+ *   src/shader/render_compose.frag:26-48  (K5: per-pixel select new vs. old rendering)
+ *
+ * GL structure replaced: the reference draws all S surfels as GL_POINTS, expands each to a
+ * screen-space quad in a geometry shader, lets the fixed-function rasteriser + 24-bit depth test
+ * pick the nearest surfel per pixel and writes three RGBA32F targets -- and does that 4 times per
+ * render() (old, new, and two dead passes into composedFrame_, quirk B-8) plus a compose pass.
+ * Here:
+ *   - ONE streaming pass over the surfel buffer (64 B per lane, grid-stride, size read from HBM)
+ *     feeds up to two z-buffers (old / new) at once;
+ *   - the triangle rasteriser is explicit: window coordinates snapped to 1/256 pixel, 64-bit
+ *     integer edge functions with an antisymmetric tie rule, affine interpolation of depth and
+ *     disc coordinates (gl_Position.w = 1 in render_surfels.geom);
+ *   - the depth test is a 64-bit atomicMin of (depth24 << 32 | surfel id): GL_LESS with in-order
+ *     primitives = smaller depth, then lower id;
+ *   - the resolve pass gathers the winning surfel's attributes, applies K5 and leaves the
+ *     z-buffers cleared for the next render (no separate clear launch).
+ */
+#include <cstring>
+
+#include "suma_internal.h"
+
+enum { TIE_LOW_INDEX = 0, TIE_HIGH_INDEX_OLD = 1, TIE_HIGH_INDEX_NEW = 2 };
+
+struct RenderSlot {
+  int enabled;
+  int mode; /* 0: old surfels (creation < thr); 1: new surfels (creation >= thr || timestamp >= thr) */
+  int tie;
+  unsigned long long* zbuf;
+  m4 inv_pose;
+};
+
+struct RenderArgs {
+  const suma_surfel* surfels;
+  const DevState* ds;
+  const float* poses;
+  proj_t q;
+  float conf_threshold;
+  int use_stability;
+  int32_t thr;
+  RenderSlot slot[2];
+};
+
+struct rvtx {
+  long long X, Y; /* window coordinates in 1/256 pixel */
+  float z, tu, tv;
+};
+
+__device__ __forceinline__ long long edge_fn(const rvtx& a, const rvtx& b, long long px, long long py) {
+  return (b.X - a.X) * (py - a.Y) - (b.Y - a.Y) * (px - a.X);
+}
+/* ownership of a pixel centre exactly on an edge: antisymmetric in the edge direction, so a
+ * pixel on the diagonal shared by the two strip triangles is produced exactly once */
+__device__ __forceinline__ bool owns_edge(const rvtx& s, const rvtx& t) {
+  long long dx = t.X - s.X, dy = t.Y - s.Y;
+  return dy > 0 || (dy == 0 && dx < 0);
+}
+
+__device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t id, int tie) {
+  /* GL_LESS, in order: equal depth keeps the earlier primitive (lower id).  GL_LEQUAL
+   * (render_composed, SurfelMap.cpp:1126): equal depth takes the later primitive, and the "new"
+   * pass is drawn after the "old" pass into the same depth buffer. */
+  if (tie == TIE_LOW_INDEX) return ((unsigned long long)z24 << 32) | id;
+  unsigned long long pass = (tie == TIE_HIGH_INDEX_OLD) ? 1u : 0u;
+  return ((unsigned long long)z24 << 33) | (pass << 32) | (unsigned long long)(0xffffffffu - id);
+}
+
+__device__ void raster_tri(rvtx A, rvtx B, rvtx C, int32_t W, int32_t H, unsigned long long* __restrict__ zbuf,
+                           uint32_t id, int tie) {
+  long long area = edge_fn(A, B, C.X, C.Y);
+  if (area == 0) return;
+  if (area < 0) {
+    rvtx t = B;
+    B = C;
+    C = t;
+    area = -area;
+  }
+  long long minX = min(A.X, min(B.X, C.X)), maxX = max(A.X, max(B.X, C.X));
+  long long minY = min(A.Y, min(B.Y, C.Y)), maxY = max(A.Y, max(B.Y, C.Y));
+  long long i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* arithmetic shift = floor */
+  long long j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
+  if (i0 < 0) i0 = 0;
+  if (j0 < 0) j0 = 0;
+  if (i1 > W - 1) i1 = W - 1;
+  if (j1 > H - 1) j1 = H - 1;
+  const bool own0 = owns_edge(B, C), own1 = owns_edge(C, A), own2 = owns_edge(A, B);
+  const float fa = (float)area;
+  for (long long j = j0; j <= j1; ++j) {
+    for (long long i = i0; i <= i1; ++i) {
+      long long px = 256 * i + 128, py = 256 * j + 128;
+      long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
+      if (!(w0 > 0 || (w0 == 0 && own0))) continue;
+      if (!(w1 > 0 || (w1 == 0 && own1))) continue;
+      if (!(w2 > 0 || (w2 == 0 && own2))) continue;
+      float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+      float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
+      float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
+      if ((tu * tu + tv * tv) > 1.0f) continue; /* render_surfels.frag:22 */
+      float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
+      if (!(z >= 0.0f && z <= 1.0f)) continue; /* near / far clipping */
+      unsigned long long key = render_key(depth24(z), id, tie);
+      atomicMin(&zbuf[(size_t)j * (size_t)W + (size_t)i], key);
+    }
+  }
+}
+
+/* (inv_pose * surfelPose) * v, render_surfels.vert:44-48 */
+__device__ __forceinline__ void surfel_to_sensor(const float* __restrict__ poses, const float* inv_pose, float count,
+                                                 v3 pos, v3 nrm, v3* p, v3* n) {
+  float Ps[16], M[16];
+  const float4* src = reinterpret_cast<const float4*>(poses + 16 * (size_t)(int32_t)count);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 col = src[k];
+    Ps[4 * k] = col.x;
+    Ps[4 * k + 1] = col.y;
+    Ps[4 * k + 2] = col.z;
+    Ps[4 * k + 3] = col.w;
+  }
+  m4_mul(inv_pose, Ps, M);
+  *p = m4_point(M, pos);
+  *n = m4_dir(M, nrm);
+}
+
+__global__ void __launch_bounds__(256) k_render(RenderArgs a) {
+  const uint32_t S = a.ds->n_surfels;
+  const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+    const float4 s0 = sf[4 * (size_t)i], s1 = sf[4 * (size_t)i + 1], s2 = sf[4 * (size_t)i + 2];
+    const float radius = s0.w, confidence = s1.w, count = s2.w;
+    const int32_t creation = (int32_t)count;
+    const int32_t ts = (int32_t)__float_as_uint(s2.x);
+    if (a.use_stability && !(confidence > a.conf_threshold)) continue;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const RenderSlot& slot = a.slot[sl];
+      if (!slot.enabled) continue;
+      const bool selected = (slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr);
+      if (!selected) continue;
+      v3 p, n;
+      surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
+      v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
+      v3 v = normalize3(cross3(n, u));
+      float lp = len3(p);
+      bool visible = dot3(n, divs3(neg3(p), lp)) > 0.01f;
+      v3 pp = project01(a.q, p);
+      if (!(visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f))
+        continue;
+      v3 ru = scale3(radius, u), rv = scale3(radius, v);
+      v3 corner[4];
+      corner[0] = sub3(sub3(p, ru), rv);
+      corner[1] = sub3(add3(p, ru), rv);
+      corner[2] = add3(sub3(p, ru), rv);
+      corner[3] = add3(add3(p, ru), rv);
+      rvtx vt[4];
+      bool bad = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        v3 pr = project01(a.q, corner[k]);
+        /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
+        if (pp.x - pr.x > 0.5f) pr.x += 1.0f;
+        if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
+        float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
+        if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
+        vt[k].X = (long long)sdm_floor(xw * 256.0f + 0.5f);
+        vt[k].Y = (long long)sdm_floor(yw * 256.0f + 0.5f);
+        vt[k].z = pr.z;
+        vt[k].tu = (k & 1) ? 1.0f : -1.0f;
+        vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+      }
+      if (bad) continue;
+      /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
+      raster_tri(vt[0], vt[1], vt[2], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
+      raster_tri(vt[2], vt[1], vt[3], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
+    }
+  }
+}
+
+__device__ __forceinline__ uint32_t key_id(unsigned long long key, int tie) {
+  uint32_t low = (uint32_t)(key & 0xffffffffull);
+  return tie == TIE_LOW_INDEX ? low : (0xffffffffu - low);
+}
+
+struct ResolveOut {
+  float4 v, n, s;
+};
+
+/* attributes of the winning surfel (render_surfels.frag:30-32): surfel-centre position, normal,
+ * semantic -- flat over the disc */
+__device__ __forceinline__ ResolveOut resolve_pixel(unsigned long long key, int tie, const suma_surfel* surfels,
+                                                    const float* poses, const float* inv_a, const float* inv_b) {
+  ResolveOut o;
+  if (key == SUMA_EMPTY_KEY) {
+    o.v = o.n = o.s = f4(0.f, 0.f, 0.f, 0.f);
+    return o;
+  }
+  uint32_t id = key_id(key, tie);
+  const float4* sf = reinterpret_cast<const float4*>(surfels) + 4 * (size_t)id;
+  float4 s0 = sf[0], s1 = sf[1], s2 = sf[2], s3 = sf[3];
+  const float* inv = inv_a;
+  if (tie != TIE_LOW_INDEX && ((key >> 32) & 1ull) == 0) inv = inv_b; /* composed: drawn by the new pass */
+  v3 p, n;
+  surfel_to_sensor(poses, inv, s2.w, xyz(s0), xyz(s1), &p, &n);
+  o.v = f4(p.x, p.y, p.z, 1.0f);
+  o.n = f4(n.x, n.y, n.z, 1.0f);
+  o.s = s3;
+  return o;
+}
+
+struct ResolveArgs {
+  const suma_surfel* surfels;
+  const float* poses;
+  unsigned long long *zbuf_a, *zbuf_b;
+  m4 inv_a, inv_b;
+  int tie;
+  uint32_t Pm;
+  float max_distance;
+  float4 *va, *na, *sa; /* targets of zbuf_a (old frame / single target); NULL = not written */
+  float4 *vb, *nb, *sb; /* targets of zbuf_b (new frame) */
+  float4 *vo, *no, *so; /* composed output (K5) */
+};
+
+/* single z-buffer -> up to three maps */
+__global__ void __launch_bounds__(256) k_resolve(ResolveArgs a) {
+  uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= a.Pm) return;
+  unsigned long long key = a.zbuf_a[pix];
+  a.zbuf_a[pix] = SUMA_EMPTY_KEY;
+  ResolveOut o = resolve_pixel(key, a.tie, a.surfels, a.poses, a.inv_a.m, a.inv_b.m);
+  if (a.va) a.va[pix] = o.v;
+  if (a.na) a.na[pix] = o.n;
+  if (a.sa) a.sa[pix] = o.s;
+}
+
+/* old + new z-buffers -> old frame, new frame and the K5 composition (render_compose.frag:26-48) */
+__global__ void __launch_bounds__(256) k_resolve_compose(ResolveArgs a) {
+  uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= a.Pm) return;
+  unsigned long long ka = a.zbuf_a[pix], kb = a.zbuf_b[pix];
+  a.zbuf_a[pix] = SUMA_EMPTY_KEY;
+  a.zbuf_b[pix] = SUMA_EMPTY_KEY;
+  ResolveOut o = resolve_pixel(ka, TIE_LOW_INDEX, a.surfels, a.poses, a.inv_a.m, a.inv_a.m);
+  ResolveOut nw = resolve_pixel(kb, TIE_LOW_INDEX, a.surfels, a.poses, a.inv_b.m, a.inv_b.m);
+  a.va[pix] = o.v;
+  a.na[pix] = o.n;
+  a.sa[pix] = o.s;
+  a.vb[pix] = nw.v;
+  a.nb[pix] = nw.n;
+  a.sb[pix] = nw.s;
+  float4 v = nw.v, n = nw.n, s = nw.s;
+  bool valid = (o.v.w > 0.5f && o.n.w > 0.5f);
+  bool new_valid = (v.w > 0.5f && n.w > 0.5f);
+  if (!new_valid && valid && (v.w < 0.5f || len3(sub3(xyz(v), xyz(o.v))) < a.max_distance)) {
+    v = o.v;
+    n = o.n;
+    s = o.s;
+  }
+  a.vo[pix] = v;
+  a.no[pix] = n;
+  a.so[pix] = s;
+}
+
+static void set_m4(m4& d, const float* s) {
+  for (int i = 0; i < 16; ++i) d.m[i] = s[i];
+}
+
+static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
+  RenderArgs a;
+  a.surfels = c->surfels[c->cur];
+  a.ds = c->ds;
+  a.poses = c->poses;
+  a.q = c->pm;
+  a.conf_threshold = conf_threshold;
+  a.use_stability = c->p.use_stability;
+  a.thr = thr;
+  a.slot[0].enabled = a.slot[1].enabled = 0;
+  return a;
+}
+static uint32_t stream_grid(suma_ctx* c) {
+  /* sized from the last surfel count the host has seen; the kernels grid-stride over the
+   * device-resident count, so a stale value only changes the number of loop trips */
+  uint64_t est = (uint64_t)c->known_surfels + 2 * c->P;
+  uint64_t blocks = (est + 255) / 256;
+  if (blocks > SUMA_STREAM_BLOCKS) blocks = SUMA_STREAM_BLOCKS;
+  if (blocks < 256) blocks = 256;
+  return (uint32_t)blocks;
+}
+static ResolveArgs resolve_args(suma_ctx* c) {
+  ResolveArgs r;
+  memset(&r, 0, sizeof(r));
+  r.surfels = c->surfels[c->cur];
+  r.poses = c->poses;
+  r.zbuf_a = c->zbuf_a;
+  r.zbuf_b = c->zbuf_b;
+  r.Pm = (uint32_t)c->Pm;
+  r.max_distance = c->p.max_loop_closure_distance;
+  return r;
+}
+
+/* SurfelMap::render(pose_old, pose_new, frame, ct), SurfelMap.cpp:847-1021 */
+hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
+                             suma_frame* out) {
+  float inv_old[16], inv_new[16];
+  rigid_inverse_f(pose_old, inv_old);
+  rigid_inverse_f(pose_new, inv_new);
+  const double S = (double)c->known_surfels;
+  const uint32_t Pm = (uint32_t)c->Pm;
+  if (c->p.compose_rendering) {
+    int32_t thr = (int32_t)(c->timestamp - 100u); /* SurfelMap.cpp:873, quirk B-7 */
+    RenderArgs a = render_args(c, conf_threshold, thr);
+    a.slot[0].enabled = 1;
+    a.slot[0].mode = 0;
+    a.slot[0].tie = TIE_LOW_INDEX;
+    a.slot[0].zbuf = c->zbuf_a;
+    set_m4(a.slot[0].inv_pose, inv_old);
+    a.slot[1].enabled = 1;
+    a.slot[1].mode = 1;
+    a.slot[1].tie = TIE_LOW_INDEX;
+    a.slot[1].zbuf = c->zbuf_b;
+    set_m4(a.slot[1].inv_pose, inv_new);
+    {
+      ProfScope ps(c, "k4_render_surfels", 64.0 * S);
+      k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+    }
+    ResolveArgs r = resolve_args(c);
+    set_m4(r.inv_a, inv_old);
+    set_m4(r.inv_b, inv_new);
+    r.va = c->old_frame->map[0];
+    r.na = c->old_frame->map[1];
+    r.sa = c->old_frame->map[2];
+    r.vb = c->new_frame->map[0];
+    r.nb = c->new_frame->map[1];
+    r.sb = c->new_frame->map[2];
+    r.vo = out->map[0];
+    r.no = out->map[1];
+    r.so = out->map[2];
+    {
+      ProfScope ps(c, "k5_resolve_compose", (16.0 + 144.0) * Pm);
+      k_resolve_compose<<<(Pm + 255) / 256, 256, 0, c->stream>>>(r);
+    }
+  } else {
+    /* SurfelMap.cpp:976-1018: one pass, threshold 0, then two frame copies */
+    RenderArgs a = render_args(c, conf_threshold, 0);
+    a.slot[0].enabled = 1;
+    a.slot[0].mode = 1;
+    a.slot[0].tie = TIE_LOW_INDEX;
+    a.slot[0].zbuf = c->zbuf_a;
+    set_m4(a.slot[0].inv_pose, inv_old);
+    {
+      ProfScope ps(c, "k4_render_surfels", 64.0 * S);
+      k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+    }
+    ResolveArgs r = resolve_args(c);
+    set_m4(r.inv_a, inv_old);
+    set_m4(r.inv_b, inv_old);
+    r.tie = TIE_LOW_INDEX;
+    r.va = out->map[0];
+    r.na = out->map[1];
+    r.sa = out->map[2];
+    {
+      ProfScope ps(c, "k5_resolve", (8.0 + 48.0) * Pm);
+      k_resolve<<<(Pm + 255) / 256, 256, 0, c->stream>>>(r);
+    }
+    size_t bytes = c->Pm * sizeof(float4);
+    for (int m = 0; m < 3; ++m) {
+      hipMemcpyAsync(c->new_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->stream);
+      hipMemcpyAsync(c->old_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->stream);
+    }
+  }
+  return hipGetLastError();
+}
+
+/* render_active (which = 1, SurfelMap.cpp:1023-1069) / render_inactive (which = 0, :1071-1114).
+ * Only COLOR0 / COLOR1 are re-attached (:1047-1048): the semantic map of the target frame is NOT
+ * refreshed by these calls; restated as such. */
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active) {
+  float inv[16];
+  rigid_inverse_f(pose, inv);
+  int32_t thr = (int32_t)(c->timestamp - 100u);
+  RenderArgs a = render_args(c, conf_threshold, thr);
+  a.slot[0].enabled = 1;
+  a.slot[0].mode = active ? 1 : 0;
+  a.slot[0].tie = TIE_LOW_INDEX;
+  a.slot[0].zbuf = c->zbuf_a;
+  set_m4(a.slot[0].inv_pose, inv);
+  {
+    ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
+    k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+  }
+  ResolveArgs r = resolve_args(c);
+  set_m4(r.inv_a, inv);
+  set_m4(r.inv_b, inv);
+  r.tie = TIE_LOW_INDEX;
+  suma_frame* tgt = active ? c->new_frame : c->old_frame;
+  r.va = tgt->map[0];
+  r.na = tgt->map[1];
+  r.sa = nullptr;
+  {
+    ProfScope ps(c, "k5_resolve", (8.0 + 32.0) * (double)c->Pm);
+    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->stream>>>(r);
+  }
+  return hipGetLastError();
+}
+
+/* render_composed, SurfelMap.cpp:1116-1165: old pass then new pass, GL_LEQUAL, one depth
+ * buffer, only the vertex / normal attachments are switched to composedFrame_ */
+hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
+                                      float conf_threshold) {
+  float inv_old[16], inv_new[16];
+  rigid_inverse_f(pose_old, inv_old);
+  rigid_inverse_f(pose_new, inv_new);
+  int32_t thr = (int32_t)(c->timestamp - 100u);
+  RenderArgs a = render_args(c, conf_threshold, thr);
+  a.slot[0].enabled = 1;
+  a.slot[0].mode = 0;
+  a.slot[0].tie = TIE_HIGH_INDEX_OLD;
+  a.slot[0].zbuf = c->zbuf_a;
+  set_m4(a.slot[0].inv_pose, inv_old);
+  a.slot[1].enabled = 1;
+  a.slot[1].mode = 1;
+  a.slot[1].tie = TIE_HIGH_INDEX_NEW;
+  a.slot[1].zbuf = c->zbuf_a;
+  set_m4(a.slot[1].inv_pose, inv_new);
+  {
+    ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
+    k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+  }
+  ResolveArgs r = resolve_args(c);
+  set_m4(r.inv_a, inv_old);
+  set_m4(r.inv_b, inv_new);
+  r.tie = TIE_HIGH_INDEX_OLD;
+  r.va = c->composed_frame->map[0];
+  r.na = c->composed_frame->map[1];
+  r.sa = nullptr;
+  {
+    ProfScope ps(c, "k5_resolve", (8.0 + 32.0) * (double)c->Pm);
+    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->stream>>>(r);
+  }
+  return hipGetLastError();
+}

@@ -1,0 +1,799 @@
+/*
+ * k_update.hip -- K7..K12: SurfelMap::update on gfx950.
+ *
+ * Replaces (reference):
+ *   SurfelMap::update                 src/core/SurfelMap.cpp:492-584
+ *   K7  renderIndexmap                SurfelMap.cpp:586-604 + src/shader/gen_indexmap.vert:62-81
+ *   K8  generateDataSurfels           SurfelMap.cpp:606-619 + init_radiusConf.vert:34-68
+ *   K9  updateSurfels (update)        SurfelMap.cpp:621-644 + update_surfels.vert:140-334,
+ *                                     update_surfels.geom:30-43, update_surfels.frag:9-12
+ *   K10 updateSurfels (initialise)    SurfelMap.cpp:646-664 + gen_surfels.vert:38-52, gen_surfels.geom:109-145
+ *   K11 copySurfels                   SurfelMap.cpp:667-698 + copy_surfels.vert:38-56
+ *   K12 extractSurfels                SurfelMap.cpp:708-742 + extract_surfels.vert:46-64
+ *
+ * GL structure replaced: transform feedback (an order-preserving append performed by the
+ * fixed-function pipeline) becomes a single-pass stable compaction: every 256-surfel tile
+ * computes its survivors, publishes its count in an 8-byte status word and obtains its output
+ * offset by a decoupled look-back over the preceding tiles' words (tile ids handed out by an
+ * atomic ticket, so predecessors are always running).  Output order = input order, exactly as
+ * transform feedback guarantees.  K11's area filter is evaluated inside K9 / K10, so the map is
+ * read once and written once per scan instead of being copied a second time:
+ *   traffic per scan = 64 B * (S + S_new) + the gathered measurement texels.
+ * Point splats with depth test (K7, the K9 integration mask) are 64-bit atomicMin / plain
+ * stores as in k_preprocess.hip.
+ */
+#include <cstring>
+
+#include "suma_internal.h"
+
+/* ---------------------------------------------------------------------------------------------
+ * decoupled look-back
+ * ------------------------------------------------------------------------------------------- */
+#define ST_AGG 1u
+#define ST_INC 2u
+
+__device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, uint32_t flag, uint32_t value) {
+  return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | value;
+}
+
+/* Called by wave 0 of a block.  Returns the number of selected items in all tiles before `tile`.
+ * Status words are single 8-byte granules carrying {epoch, flag, value}: written and read with
+ * relaxed agent-scope atomics (write-through / L1-bypassing), no fences needed because payload
+ * and flag travel in the same word.  A stale epoch means "not published yet". */
+__device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, uint32_t tile, uint32_t agg,
+                                    uint32_t epoch, int lane) {
+  if (tile == 0) {
+    if (lane == 0)
+      __hip_atomic_store(&status[0], st_pack(epoch, ST_INC, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return 0;
+  }
+  if (lane == 0)
+    __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint32_t running = 0;
+  int64_t base = (int64_t)tile - 1;
+  for (;;) {
+    int64_t idx = base - lane;
+    unsigned long long w;
+    if (idx >= 0) {
+      do {
+        w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
+    } else {
+      w = st_pack(epoch, ST_INC, 0); /* virtual tile -1 */
+    }
+    const bool inc = ((w >> 32) & 3ull) == ST_INC;
+    const unsigned long long ball = __ballot(inc);
+    uint32_t v = (uint32_t)(w & 0xffffffffull);
+    if (ball != 0) {
+      const int first = __ffsll((long long)ball) - 1; /* nearest tile with a known inclusive prefix */
+      if (lane > first) v = 0;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    running += v;
+    if (ball != 0) break;
+    base -= 64;
+  }
+  if (lane == 0)
+    __hip_atomic_store(&status[tile], st_pack(epoch, ST_INC, running + agg), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  return running;
+}
+
+/* block-level stable ranking of a flag: returns the rank of this thread among the block's
+ * selected threads and the block total; all 256 threads call it */
+struct BlockRank {
+  uint32_t rank, total;
+};
+__device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [4] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ball = __ballot(flag);
+  const uint32_t below = __popcll(ball & ((1ull << lane) - 1ull));
+  if (lane == 0) s_wave[wave] = __popcll(ball);
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    uint32_t cnt = s_wave[w];
+    if (w < wave) off += cnt;
+    tot += cnt;
+  }
+  BlockRank r;
+  r.rank = off + below;
+  r.total = tot;
+  return r;
+}
+
+/* ticket bookkeeping shared by the compaction kernels: the last block to leave re-arms the
+ * ticket and runs the finaliser */
+__device__ __forceinline__ bool block_leaves_last(DevState* ds) {
+  __shared__ int s_is_last;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t d = __hip_atomic_fetch_add(&ds->done_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_is_last = (d == gridDim.x - 1);
+  }
+  __syncthreads();
+  return s_is_last != 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * K8 + clear of the integration mask
+ * ------------------------------------------------------------------------------------------- */
+__global__ void __launch_bounds__(256)
+    k8_radius(const float4* __restrict__ V, const float4* __restrict__ N, float4* __restrict__ radius_conf,
+              uint8_t* __restrict__ integrated, uint32_t P, float pixel_size, float angle_thresh, float min_radius,
+              float max_radius, DevState* ds) {
+  uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= P) return;
+  if (pix == 0) { /* per-update counters */
+    ds->n_updated = 0;
+    ds->n_data = 0;
+    ds->n_kept_updated = 0;
+    ds->n_kept_data = 0;
+  }
+  float4 v = V[pix], n = N[pix];
+  v3 vv = xyz(v), nn = xyz(n);
+  float d = len3(vv);
+  v3 view_dir = divs3(neg3(vv), d);
+  float angle = dot3(nn, view_dir);
+  float valid = 0.0f, radius = 0.0f;
+  if (v.w > 0.5f && n.w > 0.5f && angle > angle_thresh) {
+    valid = 1.0f;
+    radius = ((1.41f * d) * pixel_size) / fclamp(dot3(nn, divs3(neg3(vv), d)), 0.5f, 1.0f);
+    radius = fmin_(fmax_(radius, min_radius), max_radius);
+  }
+  radius_conf[pix] = f4(radius, 0.0f, 0.0f, valid); /* quirk B-3: the confidence channel stays 0 */
+  integrated[pix] = 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * K7 index map: nearest visible surfel per data pixel
+ * ------------------------------------------------------------------------------------------- */
+struct UpdArgs {
+  const suma_surfel* in;
+  suma_surfel* out;
+  DevState* ds;
+  const float* poses;
+  const float* poses_inv;
+  unsigned long long* zbuf; /* data sized: K7 keys */
+  unsigned long long* status;
+  uint32_t epoch;
+  const float4 *V, *N, *Sem;
+  const float4* radius_conf;
+  uint8_t* integrated;
+  uint32_t* index_map;
+  proj_t q;
+  m4 pose, inv_pose;
+  int32_t timestamp;
+  uint32_t max_surfels;
+  /* K9 parameters (SurfelMap.cpp:399-438) */
+  float confidence_threshold, map_max_distance, update_angle_thresh;
+  float p_stable, p_unstable, log_prior, log_unstable, sigma_angle, sigma_distance, max_weight;
+  int32_t use_stability, unstable_age, confidence_mode, active_timestamps, weighting_scheme, averaging_scheme,
+      update_always;
+  /* K11 */
+  float cx, cy, extent;
+};
+
+__device__ __forceinline__ void load_pose(const float* __restrict__ table, int32_t idx, float* M) {
+  const float4* src = reinterpret_cast<const float4*>(table + 16 * (size_t)idx);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float4 col = src[k];
+    M[4 * k] = col.x;
+    M[4 * k + 1] = col.y;
+    M[4 * k + 2] = col.z;
+    M[4 * k + 3] = col.w;
+  }
+}
+
+__global__ void __launch_bounds__(256) k7_indexmap(UpdArgs a) {
+  const uint32_t S = a.ds->n_surfels;
+  const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+    float4 s0 = sf[4 * (size_t)i], s1 = sf[4 * (size_t)i + 1];
+    float count = sf[4 * (size_t)i + 2].w;
+    float Ps[16], M[16];
+    load_pose(a.poses, (int32_t)count, Ps);
+    m4_mul(a.inv_pose.m, Ps, M);
+    v3 p = m4_point(M, xyz(s0)), n = m4_dir(M, xyz(s1));
+    float lp = len3(p);
+    if (!(dot3(n, divs3(neg3(p), lp)) > 0.01f)) continue;
+    v3 pr = project01(a.q, p);
+    float fx = sdm_floor(pr.x * a.q.width), fy = sdm_floor(pr.y * a.q.height);
+    if (!(fx >= 0.0f && fx < a.q.width && fy >= 0.0f && fy < a.q.height)) continue;
+    float zn = 2.0f * pr.z - 1.0f;
+    if (!(zn >= -1.0f && zn <= 1.0f)) continue;
+    unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
+    atomicMin(&a.zbuf[(size_t)(int32_t)fy * a.q.W + (size_t)(int32_t)fx], key);
+  }
+}
+
+/* update_surfels.vert:113-124 slerp().  Documented deviation: where the GLSL would
+ * produce NaN (sin(omega) not > 0: identical normals) v0 is returned. */
+__device__ __forceinline__ v3 slerp3(v3 v0, v3 v1, float weight) {
+  float omega = sdm_acos(dot3(normalize3(v0), normalize3(v1)));
+  float so = sdm_sin(omega);
+  if (!(so > 0.0f)) return v0;
+  float eta = 1.0f / so;
+  float w0 = eta * sdm_sin(weight * omega);
+  float w1 = eta * sdm_sin((1.0f - weight) * omega);
+  return add3(scale3(w0, v0), scale3(w1, v1));
+}
+
+struct Surfel4 {
+  float4 a, b, c, d; /* pos+radius | normal+confidence | timestamp,color,weight,count | semantic */
+};
+
+/* K11 predicate, copy_surfels.vert:38-56 */
+__device__ __forceinline__ bool in_active_area(const UpdArgs& a, const Surfel4& s) {
+  float Ps[16];
+  load_pose(a.poses, (int32_t)s.c.w, Ps);
+  v3 pos = m4_point(Ps, xyz(s.a));
+  if ((int32_t)__float_as_uint(s.c.x) < 0) return false;
+  if (sdm_abs(pos.x - a.cx) > a.extent || sdm_abs(pos.y - a.cy) > a.extent) return false;
+  return true;
+}
+
+__device__ __forceinline__ void store_surfel(suma_surfel* out, uint32_t idx, const Surfel4& s) {
+  float4* o = reinterpret_cast<float4*>(out) + 4 * (size_t)idx;
+  o[0] = s.a;
+  o[1] = s.b;
+  o[2] = s.c;
+  o[3] = s.d;
+}
+
+/* K9 for one surfel: returns keep; `o` receives the updated record; *mark_pix >= 0 if the
+ * surviving surfel marks that measurement pixel as integrated */
+__device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surfel4& o, int32_t* mark_pix) {
+  const int32_t timestamp = a.timestamp;
+  const int32_t W = a.q.W, H = a.q.H;
+  const int32_t surfel_age = timestamp - (int32_t)__float_as_uint(in.c.x);
+  const int32_t creation_timestamp = (int32_t)in.c.w;
+  float Ps[16];
+  load_pose(a.poses, creation_timestamp, Ps);
+  const v3 old_position = m4_point(Ps, xyz(in.a));
+  const v3 old_normal = m4_dir(Ps, xyz(in.b));
+  const float old_radius = in.a.w, old_confidence = in.b.w, old_weight = in.c.z;
+
+  bool keep = true;
+  if (old_confidence < a.confidence_threshold && a.use_stability) keep = (surfel_age < a.unstable_age);
+  o = in;
+  o.c.y = pack_rgb(0.3f, 0.3f, 0.3f);
+
+  const v3 vertex = m4_point(a.inv_pose.m, old_position);
+  const v3 normal = normalize3(m4_dir(a.inv_pose.m, old_normal));
+  const bool visible = dot3(normal, divs3(neg3(vertex), len3(vertex))) > 0.0f;
+  const v3 pr = project01(a.q, vertex);
+  const float imx = sdm_floor(pr.x * a.q.width) + 0.5f, imy = sdm_floor(pr.y * a.q.height) + 0.5f, imz = pr.z;
+  /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
+  const bool in_tex = (imx >= 0.0f && imx < a.q.width && imy >= 0.0f && imy < a.q.height);
+  const int32_t tx = in_tex ? (int32_t)sdm_floor(imx) : -1, ty = in_tex ? (int32_t)sdm_floor(imy) : -1;
+  const float4 dv = texel(a.V, W, H, tx, ty), dn = texel(a.N, W, H, tx, ty);
+  const bool valid = (dv.w > 0.5f) && (dn.w > 0.5f);
+  /* quirk B-6: all(lessThan(img, dim)) && !all(lessThan(img, 0)) */
+  const bool inside =
+      (imx < a.q.width && imy < a.q.height && imz < 1.0f) && !(imx < 0.0f && imy < 0.0f && imz < 0.0f);
+
+  float penalty = 0.0f;
+  float update_confidence = a.log_prior;
+  bool mark = false;
+
+  if (valid && inside && visible) {
+    const float4 ds = texel(a.Sem, W, H, tx, ty);
+    const float data_label = ds.x * 255.0f, data_prob = ds.w;
+    const float model_label = in.d.x * 255.0f, model_prob = in.d.w;
+    if (sdm_round(data_label) != sdm_round(model_label)) {
+      if (is_dynamic_label(model_label)) penalty = 1.0f;
+    }
+    const v3 v = xyz(dv), n = xyz(dn);
+    const v3 v_global = m4_point(a.pose.m, v);
+    const v3 n_global = normalize3(m4_dir(a.pose.m, n));
+    const v3 view_dir = divs3(neg3(v), len3(v));
+    const float distance = sdm_abs(dot3(old_normal, sub3(v_global, old_position)));
+    const float angle = len3(cross3(n_global, old_normal));
+    const float4 rc = texel(a.radius_conf, W, H, tx, ty);
+    const float new_radius = rc.x, new_confidence = rc.y;
+
+    if ((distance < a.map_max_distance) && (angle < a.update_angle_thresh)) {
+      mark = true; /* gl_Position inside the viewport: update_surfels.vert:219 */
+      const float confidence = old_confidence + new_confidence;
+      o.b.w = confidence;
+      o.c.x = __uint_as_float((uint32_t)timestamp);
+      float avg_radius = fmin_(new_radius, old_radius);
+      avg_radius = fmax_(avg_radius, 0.0f); /* the update program's min_radius uniform is 0, SurfelMap.cpp:422 */
+      o.a.w = avg_radius;
+      keep = true;
+      o.c.y = pack_rgb(0.0f, 0.7f, 0.0f);
+      o.c.w = (float)creation_timestamp;
+
+      float pst = a.p_stable;
+      if (a.confidence_mode == 1 || a.confidence_mode == 3)
+        pst *= sdm_exp((-angle * angle) / (a.sigma_angle * a.sigma_angle));
+      if (a.confidence_mode == 2 || a.confidence_mode == 3)
+        pst *= sdm_exp((-distance * distance) / (a.sigma_distance * a.sigma_distance));
+      pst = fclamp(pst, a.p_unstable, 1.0f);
+      update_confidence = sdm_log(pst / (1.0f - pst));
+
+      if ((new_radius < old_radius && timestamp - creation_timestamp < a.active_timestamps) || a.update_always) {
+        float w1 = 0.9f, w2 = 0.1f;
+        if (a.weighting_scheme > 0) {
+          w1 = old_weight;
+          w2 = 1.0f;
+          if (a.weighting_scheme == 2) w2 = dot3(n, view_dir);
+          o.c.z = fmin_(a.max_weight, w1 + w2);
+          float sum = w1 + w2;
+          w1 /= sum;
+          w2 /= sum;
+        }
+        v3 avg_position = add3(scale3(w1, old_position), scale3(w2, v_global));
+        v3 avg_normal = slerp3(old_normal, n_global, w1);
+        float avg_prob;
+        if (sdm_round(data_label) != sdm_round(model_label))
+          avg_prob = w1 * model_prob + w2 * (1.0f - data_prob);
+        else
+          avg_prob = w1 * model_prob + w2 * data_prob;
+        o.d.w = avg_prob;
+        if (a.averaging_scheme == 1) {
+          avg_position = add3(old_position, scale3(w2 * distance, old_normal));
+          avg_normal = slerp3(old_normal, n_global, w1);
+        }
+        avg_normal = normalize3(avg_normal);
+        float Pi[16];
+        load_pose(a.poses_inv, creation_timestamp, Pi);
+        avg_position = m4_point(Pi, avg_position);
+        avg_normal = m4_dir(Pi, avg_normal);
+        o.a = f4(avg_position.x, avg_position.y, avg_position.z, avg_radius);
+        o.b = f4(avg_normal.x, avg_normal.y, avg_normal.z, confidence);
+        o.c.y = pack_rgb(1.0f, 0.0f, 1.0f);
+      }
+    } else {
+      /* K7 winner of this measurement pixel */
+      unsigned long long key = a.zbuf[(size_t)ty * W + tx];
+      int32_t idx = (key == SUMA_EMPTY_KEY) ? -1 : (int32_t)(uint32_t)(key & 0xffffffffull);
+      if (idx == (int32_t)i) {
+        update_confidence = sdm_log(a.p_unstable / (1.0f - a.p_unstable));
+        o.c.y = pack_rgb(0.0f, 1.0f, 1.0f);
+      }
+    }
+  }
+  update_confidence = update_confidence - penalty;
+  if (a.use_stability)
+    o.b.w = fmin_((old_confidence + update_confidence) - a.log_prior, 20.0f);
+  else
+    o.b.w = old_confidence;
+  if (o.b.w < a.log_unstable && a.use_stability) keep = false;
+
+  *mark_pix = -1;
+  if (keep && mark) {
+    /* the rasterised point of the surviving surfel marks the measurement as integrated; it is
+     * clipped unless z_ndc = 2*z01 - 1 lies in [-1, 1] */
+    float zn = 2.0f * imz - 1.0f;
+    if (zn >= -1.0f && zn <= 1.0f) *mark_pix = ty * W + tx;
+  }
+  return keep;
+}
+
+/* K9 (+ K11 predicate): single-pass update with stable compaction.  Tiles of 256 surfels are
+ * handed out by ticket; output offset by decoupled look-back. */
+__global__ void __launch_bounds__(256) k9_update(UpdArgs a) {
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_wave_a[4], s_wave_b[4];
+  __shared__ uint32_t s_prefix;
+  const uint32_t S = a.ds->n_surfels;
+  const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
+  const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
+  uint32_t keep_count = 0; /* thread 0: survivors before the area filter (S') */
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const uint32_t i = tile * SUMA_TILE + threadIdx.x;
+    bool keep = false, emit = false;
+    Surfel4 o;
+    if (i < S) {
+      Surfel4 in;
+      in.a = sf[4 * (size_t)i];
+      in.b = sf[4 * (size_t)i + 1];
+      in.c = sf[4 * (size_t)i + 2];
+      in.d = sf[4 * (size_t)i + 3];
+      int32_t mark_pix;
+      keep = update_one(a, i, in, o, &mark_pix);
+      if (mark_pix >= 0) a.integrated[mark_pix] = 1;
+      emit = keep && in_active_area(a, o);
+    }
+    /* S' statistics (parity with the reference's transform-feedback count) */
+    {
+      const unsigned long long kb = __ballot(keep);
+      if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(kb);
+    }
+    BlockRank br = block_rank(emit, s_wave_a); /* contains a __syncthreads */
+    if (threadIdx.x == 0) keep_count += s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
+    if (threadIdx.x < 64) {
+      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = pre;
+    }
+    __syncthreads();
+    if (emit) {
+      uint32_t dst = s_prefix + br.rank;
+      if (dst < a.max_surfels) store_surfel(a.out, dst, o);
+    }
+    if (tile == ntiles - 1 && threadIdx.x == 0) {
+      uint32_t total = s_prefix + br.total;
+      a.ds->n_kept_updated = total < a.max_surfels ? total : a.max_surfels;
+    }
+  }
+  if (threadIdx.x == 0 && keep_count)
+    __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (block_leaves_last(a.ds)) {
+    if (threadIdx.x == 0) {
+      a.ds->ticket = 0;
+      a.ds->done_blocks = 0;
+      if (ntiles == 0) a.ds->n_kept_updated = 0;
+    }
+  }
+}
+
+/* K10 (+ K11 predicate): new surfels for valid, not yet integrated, front-facing measurement
+ * pixels, in the order of vbo_img_coords_ (x-major, SurfelMap.cpp:88-92).  Appends behind the
+ * survivors of K9.  Also exports the K7 winners as a uint32 index map and leaves the z-buffer
+ * cleared for the next user. */
+__global__ void __launch_bounds__(256) k10_generate(UpdArgs a) {
+  __shared__ uint32_t s_tile;
+  __shared__ uint32_t s_wave_a[4], s_wave_b[4];
+  __shared__ uint32_t s_prefix;
+  const int32_t W = a.q.W, H = a.q.H;
+  const uint32_t P = (uint32_t)W * (uint32_t)H;
+  const uint32_t ntiles = (P + SUMA_TILE - 1) / SUMA_TILE;
+  const uint32_t base = a.ds->n_kept_updated;
+  const float color = pack_rgb(0.0f, 0.0f, 1.0f);
+  uint32_t new_count = 0;
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const uint32_t t = tile * SUMA_TILE + threadIdx.x; /* x-major item index */
+    bool gen = false, emit = false;
+    Surfel4 s;
+    if (t < P) {
+      const int32_t x = (int32_t)(t / (uint32_t)H), y = (int32_t)(t % (uint32_t)H);
+      const size_t pix = (size_t)y * W + x;
+      const float4 v = a.V[pix], n = a.N[pix], rc = a.radius_conf[pix];
+      /* export + clear of the K7 z-buffer */
+      const unsigned long long key = a.zbuf[pix];
+      a.index_map[pix] = (key == SUMA_EMPTY_KEY) ? 0u : (uint32_t)(key & 0xffffffffull) + 1u;
+      a.zbuf[pix] = SUMA_EMPTY_KEY;
+      bool invalid = (v.w < 1.0f) || (n.w < 1.0f);
+      invalid = invalid || (rc.w < 0.5f);
+      const bool integrated = a.integrated[pix] != 0;
+      const v3 vv = xyz(v), nn = xyz(n);
+      const v3 view_dir = divs3(neg3(vv), len3(vv));
+      gen = (!invalid && !integrated && (dot3(nn, view_dir) > 0.01f));
+      if (gen) {
+        const v3 ng = normalize3(nn);
+        const float4 sem = a.Sem[pix];
+        float conf = a.log_prior;
+        if (is_dynamic_label(sem.x * 255.0f)) conf = a.log_prior - 0.5f;
+        s.a = f4(v.x, v.y, v.z, rc.x);
+        s.b = f4(ng.x, ng.y, ng.z, conf);
+        s.c = f4(__uint_as_float((uint32_t)a.timestamp), color, 1.0f, (float)a.timestamp);
+        s.d = sem;
+        emit = in_active_area(a, s);
+      }
+    }
+    {
+      const unsigned long long gb = __ballot(gen);
+      if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(gb);
+    }
+    BlockRank br = block_rank(emit, s_wave_a);
+    if (threadIdx.x == 0) new_count += s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
+    if (threadIdx.x < 64) {
+      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = pre;
+    }
+    __syncthreads();
+    if (emit) {
+      uint64_t dst = (uint64_t)base + s_prefix + br.rank;
+      if (dst < a.max_surfels) store_surfel(a.out, (uint32_t)dst, s);
+    }
+    if (tile == ntiles - 1 && threadIdx.x == 0) {
+      uint64_t kept = (uint64_t)s_prefix + br.total;
+      uint64_t total = (uint64_t)base + kept;
+      a.ds->n_kept_data = (uint32_t)kept;
+      if (total > a.max_surfels) {
+        total = a.max_surfels;
+        atomicOr(&a.ds->overflow, 1u);
+      }
+      a.ds->n_surfels = (uint32_t)total; /* the compaction target becomes the active map */
+    }
+  }
+  if (threadIdx.x == 0 && new_count)
+    __hip_atomic_fetch_add(&a.ds->n_data, new_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (block_leaves_last(a.ds)) {
+    if (threadIdx.x == 0) {
+      a.ds->ticket = 0;
+      a.ds->done_blocks = 0;
+    }
+  }
+}
+
+static void set_m4(m4& d, const float* s) {
+  for (int i = 0; i < 16; ++i) d.m[i] = s[i];
+}
+
+static uint32_t stream_grid(suma_ctx* c, uint64_t items) {
+  uint64_t blocks = (items + 255) / 256;
+  if (blocks > SUMA_STREAM_BLOCKS) blocks = SUMA_STREAM_BLOCKS;
+  if (blocks < 256) blocks = 256;
+  return (uint32_t)blocks;
+}
+
+/* K7..K11 of SurfelMap::update for the current map (c->surfels[c->cur]); the result lands in the
+ * other buffer, which the caller makes current. */
+hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
+                             float cy, float extent) {
+  const uint32_t P = (uint32_t)c->P;
+  const double S = (double)c->known_surfels;
+  UpdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = c->surfels[c->cur];
+  a.out = c->surfels[c->cur ^ 1];
+  a.ds = c->ds;
+  a.poses = c->poses;
+  a.poses_inv = c->poses_inv;
+  a.zbuf = c->zbuf_data;
+  a.status = c->tile_status;
+  a.V = f->map[SUMA_MAP_VERTEX];
+  a.N = f->map[SUMA_MAP_NORMAL];
+  a.Sem = f->map[SUMA_MAP_SEMANTIC];
+  a.radius_conf = c->radius_conf;
+  a.integrated = c->integrated;
+  a.index_map = c->index_map;
+  a.q = c->pd;
+  set_m4(a.pose, pose);
+  set_m4(a.inv_pose, inv_pose);
+  a.timestamp = (int32_t)c->timestamp;
+  a.max_surfels = c->p.max_surfels;
+  a.confidence_threshold = c->p.confidence_threshold;
+  a.map_max_distance = c->p.map_max_distance;
+  a.update_angle_thresh = c->mc.update_angle_thresh;
+  a.p_stable = c->p.p_stable;
+  a.p_unstable = c->mc.p_unstable;
+  a.log_prior = c->mc.log_prior;
+  a.log_unstable = c->mc.log_unstable;
+  a.sigma_angle = c->p.sigma_angle;
+  a.sigma_distance = c->p.sigma_distance;
+  a.max_weight = c->p.max_weight;
+  a.use_stability = c->p.use_stability;
+  a.unstable_age = c->p.unstable_age;
+  a.confidence_mode = c->p.confidence_mode;
+  a.active_timestamps = c->p.active_timestamps;
+  a.weighting_scheme = c->p.weighting_scheme;
+  a.averaging_scheme = c->p.averaging_scheme;
+  a.update_always = c->p.update_always;
+  a.cx = cx;
+  a.cy = cy;
+  a.extent = extent;
+  hipStream_t st = c->stream;
+  const uint32_t gridS = stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
+  {
+    ProfScope ps(c, "k8_radius", 48.0 * P);
+    k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, c->radius_conf, c->integrated, P, c->mc.pixel_size,
+                                                c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds);
+  }
+  {
+    ProfScope ps(c, "k7_indexmap", 64.0 * S + 8.0 * P);
+    k7_indexmap<<<gridS, 256, 0, st>>>(a);
+  }
+  {
+    ProfScope ps(c, "k9_update_surfels", 128.0 * S + 16.0 * P);
+    a.epoch = ++c->epoch;
+    k9_update<<<gridS, 256, 0, st>>>(a);
+  }
+  {
+    ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);
+    a.epoch = ++c->epoch;
+    k10_generate<<<stream_grid(c, P), 256, 0, st>>>(a);
+  }
+  return hipGetLastError();
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * pose table (SurfelMap.cpp:494-495, 485-490): poses and their rigid inverses
+ * ------------------------------------------------------------------------------------------- */
+/* inverse of a rigid transform evaluated in double from the fp32 matrix, rounded once:
+ * R^T, -R^T t (the reference uses a general inverse, update_surfels.vert:197; equal to fp32
+ * rounding on rigid poses) */
+__device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
+  double R[9], t[3];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
+  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
+  for (int r = 0; r < 3; ++r) {
+    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
+    out[12 + r] = (float)(-s);
+  }
+  out[3] = out[7] = out[11] = 0.0f;
+  out[15] = 1.0f;
+}
+
+__global__ void k_set_pose1(float* poses, float* poses_inv, uint32_t idx, m4 pose) {
+  if (threadIdx.x != 0) return;
+  float inv[16];
+  rigid_inverse_dev(pose.m, inv);
+  for (int i = 0; i < 16; ++i) {
+    poses[16 * (size_t)idx + i] = pose.m[i];
+    poses_inv[16 * (size_t)idx + i] = inv[i];
+  }
+}
+__global__ void k_set_poses(float* poses, float* poses_inv, const float* src, uint32_t first, uint32_t n) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  float m[16], inv[16];
+  for (int i = 0; i < 16; ++i) m[i] = src[16 * (size_t)k + i];
+  rigid_inverse_dev(m, inv);
+  for (int i = 0; i < 16; ++i) {
+    poses[16 * (size_t)(first + k) + i] = m[i];
+    poses_inv[16 * (size_t)(first + k) + i] = inv[i];
+  }
+}
+__global__ void k_identity_poses(float* poses, float* poses_inv, uint32_t n) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  for (int i = 0; i < 16; ++i) {
+    float v = (i % 5 == 0) ? 1.0f : 0.0f;
+    poses[16 * (size_t)k + i] = v;
+    poses_inv[16 * (size_t)k + i] = v;
+  }
+}
+
+hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16) {
+  m4 p;
+  set_m4(p, pose16);
+  k_set_pose1<<<1, 64, 0, c->stream>>>(c->poses, c->poses_inv, idx, p);
+  return hipGetLastError();
+}
+hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n) {
+  if (n == 0) return hipSuccess;
+  k_set_poses<<<(n + 255) / 256, 256, 0, c->stream>>>(c->poses, c->poses_inv, d_src, first, n);
+  return hipGetLastError();
+}
+hipError_t launch_fill_identity_poses(suma_ctx* c) {
+  uint32_t n = c->p.max_poses;
+  k_identity_poses<<<(n + 255) / 256, 256, 0, c->stream>>>(c->poses, c->poses_inv, n);
+  return hipGetLastError();
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * K12 + submap cache (device arena)
+ * ------------------------------------------------------------------------------------------- */
+struct ExtractArgs {
+  const suma_surfel* in;
+  suma_surfel* arena;
+  DevState* ds;
+  CacheSlot* slots;
+  const float* poses;
+  unsigned long long* status;
+  uint32_t epoch, slot, arena_cap;
+  float cx, cy, extent;
+};
+
+/* extract_surfels.vert:46-64: stable compaction of the surfels of one submap tile into the
+ * cache arena (capacity SUMA_EXTRACT_CAPACITY per tile, SurfelMap.cpp:279) */
+__global__ void __launch_bounds__(256) k12_extract(ExtractArgs a) {
+  __shared__ uint32_t s_tile, s_prefix, s_base;
+  __shared__ uint32_t s_wave[4];
+  const uint32_t S = a.ds->n_surfels;
+  const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
+  const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
+  const uint32_t base = a.ds->cache_used; /* stable during the kernel: only the finaliser moves it */
+  for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0)
+      s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    if (tile >= ntiles) break;
+    const uint32_t i = tile * SUMA_TILE + threadIdx.x;
+    bool sel = false;
+    Surfel4 s;
+    if (i < S) {
+      s.a = sf[4 * (size_t)i];
+      s.b = sf[4 * (size_t)i + 1];
+      s.c = sf[4 * (size_t)i + 2];
+      s.d = sf[4 * (size_t)i + 3];
+      float Ps[16];
+      load_pose(a.poses, (int32_t)s.c.w, Ps);
+      v3 pos = m4_point(Ps, xyz(s.a));
+      sel = !(sdm_abs(pos.x - a.cx) > a.extent || sdm_abs(pos.y - a.cy) > a.extent);
+    }
+    BlockRank br = block_rank(sel, s_wave);
+    if (threadIdx.x < 64) {
+      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      if (threadIdx.x == 0) s_prefix = pre;
+    }
+    __syncthreads();
+    if (sel) {
+      uint32_t k = s_prefix + br.rank;
+      if (k < SUMA_EXTRACT_CAPACITY && (uint64_t)base + k < a.arena_cap) store_surfel(a.arena, base + k, s);
+    }
+    if (tile == ntiles - 1 && threadIdx.x == 0) a.ds->n_extracted = s_prefix + br.total;
+  }
+  (void)s_base;
+  if (block_leaves_last(a.ds)) {
+    if (threadIdx.x == 0) {
+      a.ds->ticket = 0;
+      a.ds->done_blocks = 0;
+      uint32_t n = (ntiles == 0) ? 0u : a.ds->n_extracted;
+      if (n > SUMA_EXTRACT_CAPACITY) {
+        n = SUMA_EXTRACT_CAPACITY;
+        atomicOr(&a.ds->overflow, 4u);
+      }
+      if ((uint64_t)base + n > a.arena_cap) {
+        n = a.arena_cap - base;
+        atomicOr(&a.ds->overflow, 2u);
+      }
+      a.slots[a.slot].offset = base;
+      a.slots[a.slot].count = n;
+      a.ds->cache_used = base + n;
+      a.ds->n_extracted = n;
+    }
+  }
+}
+
+hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent) {
+  ExtractArgs a;
+  a.in = c->surfels[c->cur];
+  a.arena = c->cache_arena;
+  a.ds = c->ds;
+  a.slots = c->cache_slots;
+  a.poses = c->poses;
+  a.status = c->tile_status;
+  a.epoch = ++c->epoch;
+  a.slot = slot;
+  a.arena_cap = c->cache_cap;
+  a.cx = cx;
+  a.cy = cy;
+  a.extent = extent;
+  ProfScope ps(c, "k12_extract_submap", 64.0 * (double)c->known_surfels);
+  k12_extract<<<stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P), 256, 0, c->stream>>>(a);
+  return hipGetLastError();
+}
+
+/* append the cached surfels of one tile to the active map (SurfelMap.cpp:775-780, 801-806) */
+__global__ void __launch_bounds__(256)
+    k_append_cached(suma_surfel* surfels, const suma_surfel* arena, DevState* ds, const CacheSlot* slots,
+                    uint32_t slot, uint32_t max_surfels) {
+  const CacheSlot cs = slots[slot];
+  const uint32_t S = ds->n_surfels;
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(arena + cs.offset);
+  float4* __restrict__ dst = reinterpret_cast<float4*>(surfels);
+  uint32_t n = cs.count;
+  if ((uint64_t)S + n > max_surfels) n = max_surfels - S;
+  for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < 4ull * n; k += (uint64_t)gridDim.x * blockDim.x)
+    dst[4ull * S + k] = src[k];
+}
+__global__ void k_append_commit(DevState* ds, const CacheSlot* slots, uint32_t slot, uint32_t max_surfels) {
+  uint32_t S = ds->n_surfels, n = slots[slot].count;
+  if ((uint64_t)S + n > max_surfels) {
+    n = max_surfels - S;
+    atomicOr(&ds->overflow, 1u);
+  }
+  ds->n_surfels = S + n;
+}
+
+hipError_t launch_append_cached(suma_ctx* c, uint32_t slot) {
+  k_append_cached<<<1024, 256, 0, c->stream>>>(c->surfels[c->cur], c->cache_arena, c->ds, c->cache_slots, slot,
+                                               c->p.max_surfels);
+  k_append_commit<<<1, 1, 0, c->stream>>>(c->ds, c->cache_slots, slot, c->p.max_surfels);
+  return hipGetLastError();
+}

@@ -1,0 +1,972 @@
+/*
+ * suma_api.hip -- the C-ABI of include/suma_hip.h: context / frame management, the host side of
+ * Preprocessing, Frame2Model + LieGaussNewton and SurfelMap, and the per-scan sequencing of
+ * SurfelMapping::processScan (reference src/core/SurfelMapping.cpp:175-210, 323-358, 372-476,
+ * 797-804).  Host logic only; all arithmetic on scan data runs in the kernels of k_*.hip.
+ */
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "suma_internal.h"
+
+static thread_local std::string g_create_error;
+
+extern "C" const char* suma_version(void) { return "suma-hip 0.1 (gfx950)"; }
+extern "C" const char* suma_last_error(const suma_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+/* ---------------------------------------------------------------------------------------------
+ * helpers
+ * ------------------------------------------------------------------------------------------- */
+void rigid_inverse_f(const float* m, float* out) {
+  double R[9], t[3];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
+  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
+  for (int r = 0; r < 3; ++r) {
+    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
+    out[12 + r] = (float)(-s);
+  }
+  out[3] = out[7] = out[11] = 0.0f;
+  out[15] = 1.0f;
+}
+
+static float deg2rad_f(float deg) { return (float)((double)deg * M_PI / 180.0); }
+
+/* derived constants exactly as the reference's setParameters() compute them
+ * (Preprocessing.cpp:77-100, SurfelMap.cpp:336-457) */
+static void derive(suma_ctx* c) {
+  const suma_params& p = c->p;
+  c->pd.fov_up = fabsf(p.data_fov_up);
+  c->pd.fov = fabsf(fabsf(p.data_fov_up)) + fabsf(fabsf(p.data_fov_down));
+  c->pd.min_depth = p.min_depth;
+  c->pd.max_depth = p.max_depth;
+  c->pd.width = (float)p.data_width;
+  c->pd.height = (float)p.data_height;
+  c->pd.W = (int32_t)p.data_width;
+  c->pd.H = (int32_t)p.data_height;
+  c->pm.fov_up = fabsf(p.model_fov_up);
+  c->pm.fov = fabsf(fabsf(p.model_fov_up)) + fabsf(fabsf(p.model_fov_down));
+  c->pm.min_depth = p.model_min_depth;
+  c->pm.max_depth = p.model_max_depth;
+  c->pm.width = (float)p.model_width;
+  c->pm.height = (float)p.model_height;
+  c->pm.W = (int32_t)p.model_width;
+  c->pm.H = (int32_t)p.model_height;
+  float vfov = fabsf(p.data_fov_up) + fabsf(p.data_fov_down);
+  float hfov = 360.0f;
+  float vpix = (float)tan((double)(0.5f * deg2rad_f(vfov) / (float)p.data_height));
+  float hpix = (float)tan((double)(0.5f * deg2rad_f(hfov) / (float)p.data_width));
+  c->mc.pixel_size = vpix < hpix ? hpix : vpix;
+  c->mc.p_unstable = 1.0f - p.p_stable;
+  c->mc.log_prior = (float)log((double)p.p_prior / (1.0 - (double)p.p_prior));
+  c->mc.log_unstable = (float)log((double)c->mc.p_unstable / (1.0 - (double)c->mc.p_unstable));
+  c->mc.radconf_angle_thresh = (float)cos((double)deg2rad_f(p.max_angle));
+  c->mc.update_angle_thresh = (float)sin((double)deg2rad_f(p.map_max_angle));
+}
+
+#define CK(expr)                                                                 \
+  do {                                                                           \
+    hipError_t e__ = (expr);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      c->err = std::string(#expr) + ": " + hipGetErrorString(e__);               \
+      return SUMA_ERR_HIP;                                                       \
+    }                                                                            \
+  } while (0)
+
+static int fail(suma_ctx* c, int code, const char* msg) {
+  c->err = msg;
+  return code;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * profiling
+ * ------------------------------------------------------------------------------------------- */
+int prof_begin(suma_ctx* c, const char* name, double bytes) {
+  int id = -1;
+  for (size_t i = 0; i < c->prof_names.size(); ++i)
+    if (c->prof_names[i] == name) id = (int)i;
+  if (id < 0) {
+    id = (int)c->prof_names.size();
+    c->prof_names.push_back(name);
+    c->prof_ms.push_back(0.0);
+    c->prof_bytes.push_back(0.0);
+    c->prof_launches.push_back(0);
+  }
+  ProfEvent ev;
+  ev.id = id;
+  ev.bytes = bytes;
+  if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return -1;
+  hipEventRecord(ev.a, c->stream);
+  c->prof_events.push_back(ev);
+  return (int)c->prof_events.size() - 1;
+}
+void prof_end(suma_ctx* c, int token) { hipEventRecord(c->prof_events[token].b, c->stream); }
+
+static void prof_collect(suma_ctx* c) {
+  if (c->prof_events.empty()) return;
+  hipStreamSynchronize(c->stream);
+  for (auto& ev : c->prof_events) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
+      c->prof_ms[ev.id] += ms;
+      c->prof_bytes[ev.id] += ev.bytes;
+      c->prof_launches[ev.id] += 1;
+    }
+    hipEventDestroy(ev.a);
+    hipEventDestroy(ev.b);
+  }
+  c->prof_events.clear();
+}
+
+extern "C" int suma_profile_enable(suma_ctx* c, int on) {
+  if (!c) return SUMA_ERR_INVALID;
+  prof_collect(c);
+  c->profiling = on != 0;
+  return SUMA_OK;
+}
+extern "C" int suma_profile_reset(suma_ctx* c) {
+  if (!c) return SUMA_ERR_INVALID;
+  prof_collect(c);
+  for (size_t i = 0; i < c->prof_ms.size(); ++i) {
+    c->prof_ms[i] = 0.0;
+    c->prof_bytes[i] = 0.0;
+    c->prof_launches[i] = 0;
+  }
+  return SUMA_OK;
+}
+extern "C" int suma_profile_get(suma_ctx* c, suma_kernel_time* out, uint32_t cap) {
+  if (!c) return SUMA_ERR_INVALID;
+  prof_collect(c);
+  uint32_t n = (uint32_t)c->prof_names.size();
+  for (uint32_t i = 0; i < n && i < cap; ++i) {
+    memset(&out[i], 0, sizeof(out[i]));
+    snprintf(out[i].name, sizeof(out[i].name), "%s", c->prof_names[i].c_str());
+    out[i].launches = c->prof_launches[i];
+    out[i].total_ms = c->prof_ms[i];
+    out[i].bytes = c->prof_bytes[i];
+  }
+  return (int)n;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * context
+ * ------------------------------------------------------------------------------------------- */
+static int frame_create_raw(suma_ctx* c, uint32_t w, uint32_t h, suma_frame** out) {
+  suma_frame* f = new (std::nothrow) suma_frame();
+  if (!f) return fail(c, SUMA_ERR_NOMEM, "out of host memory");
+  f->ctx = c;
+  f->width = w;
+  f->height = h;
+  size_t P = (size_t)w * h;
+  float4* base = nullptr;
+  hipError_t e = hipMalloc((void**)&base, 3 * P * sizeof(float4));
+  if (e != hipSuccess) {
+    delete f;
+    c->err = std::string("hipMalloc(frame): ") + hipGetErrorString(e);
+    return SUMA_ERR_HIP;
+  }
+  hipMemsetAsync(base, 0, 3 * P * sizeof(float4), c->stream);
+  for (int m = 0; m < 3; ++m) f->map[m] = base + m * P;
+  *out = f;
+  return SUMA_OK;
+}
+
+static int read_state(suma_ctx* c) {
+  CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  c->known_surfels = c->h_ds->n_surfels;
+  return SUMA_OK;
+}
+
+static int map_reset_impl(suma_ctx* c) {
+  CK(hipMemsetAsync(c->ds, 0, sizeof(DevState), c->stream));
+  CK(launch_fill_identity_poses(c));
+  c->timestamp = 0;
+  c->cur = 0;
+  c->origin_i = c->origin_j = 0;
+  c->cache_index.clear();
+  c->extraction.clear();
+  c->known_surfels = 0;
+  return SUMA_OK;
+}
+
+extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_ctx** out) {
+  if (!params || !out) {
+    g_create_error = "suma_ctx_create: null argument";
+    return SUMA_ERR_INVALID;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    g_create_error = std::string("no HIP device available (") + hipGetErrorString(e) +
+                     "); this library has no CPU fallback";
+    return SUMA_ERR_HIP;
+  }
+  if (hip_device < 0 || hip_device >= ndev) {
+    g_create_error = "suma_ctx_create: device index out of range";
+    return SUMA_ERR_INVALID;
+  }
+  if (params->data_width == 0 || params->data_height == 0 || params->model_width == 0 || params->model_height == 0 ||
+      params->max_surfels == 0 || params->max_poses == 0) {
+    g_create_error = "suma_ctx_create: zero image size or capacity";
+    return SUMA_ERR_INVALID;
+  }
+  suma_ctx* c = new (std::nothrow) suma_ctx();
+  if (!c) {
+    g_create_error = "out of host memory";
+    return SUMA_ERR_NOMEM;
+  }
+  c->p = *params;
+  c->device = hip_device;
+  c->profiling = false;
+  c->epoch = 0;
+  c->scan_cap = 0;
+  c->scan_points = nullptr;
+  c->scan_labels = c->scan_probs = nullptr;
+  c->icp_current = c->icp_model = nullptr;
+  derive(c);
+  c->P = (size_t)params->data_width * params->data_height;
+  c->Pm = (size_t)params->model_width * params->model_height;
+  int rc = SUMA_OK;
+  auto body = [&]() -> int {
+    CK(hipSetDevice(hip_device));
+    CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const size_t P = c->P, Pm = c->Pm;
+    CK(hipMalloc((void**)&c->zbuf_data, P * 8));
+    CK(hipMemsetAsync(c->zbuf_data, 0xFF, P * 8, c->stream));
+    CK(hipMalloc((void**)&c->eroded, P * sizeof(float4)));
+    CK(hipMalloc((void**)&c->radius_conf, P * sizeof(float4)));
+    CK(hipMemsetAsync(c->radius_conf, 0, P * sizeof(float4), c->stream));
+    CK(hipMalloc((void**)&c->integrated, P));
+    CK(hipMemsetAsync(c->integrated, 0, P, c->stream));
+    CK(hipMalloc((void**)&c->index_map, P * 4));
+    CK(hipMemsetAsync(c->index_map, 0, P * 4, c->stream));
+    CK(hipMalloc((void**)&c->zbuf_a, Pm * 8));
+    CK(hipMalloc((void**)&c->zbuf_b, Pm * 8));
+    CK(hipMemsetAsync(c->zbuf_a, 0xFF, Pm * 8, c->stream));
+    CK(hipMemsetAsync(c->zbuf_b, 0xFF, Pm * 8, c->stream));
+    for (int b = 0; b < 2; ++b) CK(hipMalloc((void**)&c->surfels[b], (size_t)params->max_surfels * sizeof(suma_surfel)));
+    CK(hipMalloc((void**)&c->poses, (size_t)params->max_poses * 16 * sizeof(float)));
+    CK(hipMalloc((void**)&c->poses_inv, (size_t)params->max_poses * 16 * sizeof(float)));
+    c->n_tiles_cap = (uint32_t)(((size_t)params->max_surfels + 2 * P) / SUMA_TILE + 2);
+    CK(hipMalloc((void**)&c->tile_status, (size_t)c->n_tiles_cap * 8));
+    CK(hipMemsetAsync(c->tile_status, 0, (size_t)c->n_tiles_cap * 8, c->stream));
+    CK(hipMalloc((void**)&c->ds, sizeof(DevState)));
+    CK(hipHostMalloc((void**)&c->h_ds, sizeof(DevState), hipHostMallocDefault));
+    memset(c->h_ds, 0, sizeof(DevState));
+    /* ICP */
+    c->icp_blocks = 256;
+    CK(hipMalloc((void**)&c->gn, SUMA_MAX_HYP * sizeof(GnState)));
+    CK(hipMemsetAsync(c->gn, 0, SUMA_MAX_HYP * sizeof(GnState), c->stream));
+    CK(hipMalloc((void**)&c->gn_partial, (size_t)SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS * sizeof(int64_t)));
+    c->gn_history_cap = 1025;
+    CK(hipMalloc((void**)&c->gn_history, (size_t)c->gn_history_cap * 16 * sizeof(double)));
+    CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
+    CK(hipHostMalloc((void**)&c->h_gn, SUMA_MAX_HYP * sizeof(GnState), hipHostMallocDefault));
+    /* submap cache arena */
+    uint64_t cache = params->cache_surfels ? params->cache_surfels : 4ull * params->max_surfels;
+    if (cache > 0xffffffffull) cache = 0xffffffffull;
+    c->cache_cap = (uint32_t)cache;
+    CK(hipMalloc((void**)&c->cache_arena, (size_t)c->cache_cap * sizeof(suma_surfel)));
+    c->cache_slots_cap = 65536;
+    CK(hipMalloc((void**)&c->cache_slots, (size_t)c->cache_slots_cap * sizeof(CacheSlot)));
+    CK(hipMemsetAsync(c->cache_slots, 0, (size_t)c->cache_slots_cap * sizeof(CacheSlot), c->stream));
+    int r = frame_create_raw(c, params->model_width, params->model_height, &c->old_frame);
+    if (r) return r;
+    r = frame_create_raw(c, params->model_width, params->model_height, &c->new_frame);
+    if (r) return r;
+    r = frame_create_raw(c, params->model_width, params->model_height, &c->composed_frame);
+    if (r) return r;
+    r = map_reset_impl(c);
+    if (r) return r;
+    CK(hipStreamSynchronize(c->stream));
+    return SUMA_OK;
+  };
+  rc = body();
+  if (rc != SUMA_OK) {
+    g_create_error = c->err;
+    suma_ctx_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return SUMA_OK;
+}
+
+extern "C" void suma_ctx_destroy(suma_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  for (auto& ev : c->prof_events) {
+    hipEventDestroy(ev.a);
+    hipEventDestroy(ev.b);
+  }
+  void* dev[] = {c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
+                 c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status,
+                 c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
+                 c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs};
+  for (void* p : dev)
+    if (p) hipFree(p);
+  if (c->h_ds) hipHostFree(c->h_ds);
+  if (c->h_gn) hipHostFree(c->h_gn);
+  suma_frame_destroy(c->old_frame);
+  suma_frame_destroy(c->new_frame);
+  suma_frame_destroy(c->composed_frame);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int suma_set_params(suma_ctx* c, const suma_params* p) {
+  if (!c || !p) return SUMA_ERR_INVALID;
+  if (p->data_width != c->p.data_width || p->data_height != c->p.data_height || p->model_width != c->p.model_width ||
+      p->model_height != c->p.model_height || p->max_surfels != c->p.max_surfels || p->max_poses != c->p.max_poses)
+    return fail(c, SUMA_ERR_INVALID, "suma_set_params: image sizes and capacities are fixed at creation");
+  uint32_t cache = c->p.cache_surfels;
+  c->p = *p;
+  c->p.cache_surfels = cache;
+  derive(c);
+  return SUMA_OK;
+}
+extern "C" int suma_synchronize(suma_ctx* c) {
+  if (!c) return SUMA_ERR_INVALID;
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" void* suma_ctx_stream(suma_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+/* ---------------------------------------------------------------------------------------------
+ * frames
+ * ------------------------------------------------------------------------------------------- */
+extern "C" int suma_frame_create(suma_ctx* c, uint32_t w, uint32_t h, suma_frame** out) {
+  if (!c || !out || w == 0 || h == 0) return SUMA_ERR_INVALID;
+  return frame_create_raw(c, w, h, out);
+}
+extern "C" void suma_frame_destroy(suma_frame* f) {
+  if (!f) return;
+  if (f->map[0]) hipFree(f->map[0]);
+  delete f;
+}
+extern "C" int suma_frame_copy(suma_ctx* c, suma_frame* dst, const suma_frame* src) {
+  if (!c || !dst || !src || dst->width != src->width || dst->height != src->height) return SUMA_ERR_INVALID;
+  size_t bytes = 3 * (size_t)src->width * src->height * sizeof(float4);
+  CK(hipMemcpyAsync(dst->map[0], src->map[0], bytes, hipMemcpyDeviceToDevice, c->stream));
+  return SUMA_OK;
+}
+extern "C" int suma_frame_download(suma_ctx* c, const suma_frame* f, int which, suma_float4* host) {
+  if (!c || !f || !host || which < 0 || which > 2) return SUMA_ERR_INVALID;
+  size_t bytes = (size_t)f->width * f->height * sizeof(float4);
+  CK(hipMemcpyAsync(host, f->map[which], bytes, hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" int suma_frame_upload(suma_ctx* c, suma_frame* f, int which, const suma_float4* host) {
+  if (!c || !f || !host || which < 0 || which > 2) return SUMA_ERR_INVALID;
+  size_t bytes = (size_t)f->width * f->height * sizeof(float4);
+  CK(hipMemcpyAsync(f->map[which], host, bytes, hipMemcpyHostToDevice, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" uint32_t suma_frame_width(const suma_frame* f) { return f ? f->width : 0; }
+extern "C" uint32_t suma_frame_height(const suma_frame* f) { return f ? f->height : 0; }
+extern "C" void* suma_frame_device_ptr(const suma_frame* f, int which) {
+  return (f && which >= 0 && which <= 2) ? (void*)f->map[which] : nullptr;
+}
+
+extern "C" int suma_device_alloc(suma_ctx* c, uint64_t bytes, void** d_ptr) {
+  if (!c || !d_ptr) return SUMA_ERR_INVALID;
+  CK(hipMalloc(d_ptr, bytes ? bytes : 16));
+  return SUMA_OK;
+}
+extern "C" int suma_device_free(suma_ctx* c, void* d_ptr) {
+  if (!c) return SUMA_ERR_INVALID;
+  CK(hipFree(d_ptr));
+  return SUMA_OK;
+}
+extern "C" int suma_device_upload(suma_ctx* c, void* d_dst, const void* host_src, uint64_t bytes) {
+  if (!c || !d_dst || !host_src) return SUMA_ERR_INVALID;
+  CK(hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Preprocessing::process
+ * ------------------------------------------------------------------------------------------- */
+extern "C" int suma_preprocess_device(suma_ctx* c, const suma_float4* d_points, const float* d_labels,
+                                      const float* d_probs, uint32_t n, uint32_t timestamp, suma_frame* out) {
+  if (!c || !out || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
+  if (out->width != c->p.data_width || out->height != c->p.data_height)
+    return fail(c, SUMA_ERR_INVALID, "suma_preprocess: frame size differs from data_width x data_height");
+  CK(launch_preprocess(c, (const float4*)d_points, d_labels, d_probs, n, timestamp, out));
+  return SUMA_OK;
+}
+
+static int stage_scan(suma_ctx* c, const suma_float4* points, const float* labels, const float* probs, uint32_t n) {
+  if (n > c->scan_cap) {
+    if (c->scan_points) hipFree(c->scan_points);
+    if (c->scan_labels) hipFree(c->scan_labels);
+    if (c->scan_probs) hipFree(c->scan_probs);
+    c->scan_points = nullptr;
+    c->scan_labels = c->scan_probs = nullptr;
+    uint32_t cap = n + n / 4 + 1024;
+    CK(hipMalloc((void**)&c->scan_points, (size_t)cap * sizeof(float4)));
+    CK(hipMalloc((void**)&c->scan_labels, (size_t)cap * sizeof(float)));
+    CK(hipMalloc((void**)&c->scan_probs, (size_t)cap * sizeof(float)));
+    c->scan_cap = cap;
+  }
+  if (n == 0) return SUMA_OK;
+  CK(hipMemcpyAsync(c->scan_points, points, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
+  if (labels) CK(hipMemcpyAsync(c->scan_labels, labels, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  if (probs) CK(hipMemcpyAsync(c->scan_probs, probs, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  return SUMA_OK;
+}
+
+extern "C" int suma_preprocess(suma_ctx* c, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, uint32_t timestamp, suma_frame* out) {
+  if (!c || !out || (n > 0 && !points)) return SUMA_ERR_INVALID;
+  int r = stage_scan(c, points, labels, probs, n);
+  if (r) return r;
+  return suma_preprocess_device(c, (const suma_float4*)c->scan_points, labels ? c->scan_labels : nullptr,
+                                probs ? c->scan_probs : nullptr, n, timestamp, out);
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Frame2Model + LieGaussNewton
+ * ------------------------------------------------------------------------------------------- */
+extern "C" int suma_icp_set_data(suma_ctx* c, const suma_frame* current, const suma_frame* model) {
+  if (!c || !current || !model) return SUMA_ERR_INVALID;
+  c->icp_current = current;
+  c->icp_model = model;
+  return SUMA_OK;
+}
+
+static void fill_stats(const GnState& g, suma_icp_stats* st) {
+  if (!st) return;
+  st->error = g.F;
+  st->inlier_residual = g.F_inlier;
+  st->valid = g.valid;
+  st->outlier = g.outlier;
+  st->inlier = g.valid - g.outlier;
+  st->invalid = g.invalid;
+  st->iterations = g.k;
+  st->converged = g.converged;
+}
+
+extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], uint32_t iteration, double JtJ[36],
+                                          double Jtr[6], int64_t* acc, suma_icp_stats* stats) {
+  if (!c || !pose) return SUMA_ERR_INVALID;
+  if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
+  CK(launch_gn_init(c, pose, 1, 0, iteration));
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0));
+  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  const GnState& g = c->h_gn[0];
+  if (JtJ) memcpy(JtJ, g.JtJ, sizeof(g.JtJ));
+  if (Jtr) memcpy(Jtr, g.Jtr, sizeof(g.Jtr));
+  if (acc) memcpy(acc, g.acc, sizeof(g.acc));
+  fill_stats(g, stats);
+  if (stats) stats->iterations = 0;
+  return SUMA_OK;
+}
+
+/* enqueue one whole minimisation (no host round trip inside) */
+static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history) {
+  uint32_t max_iter = c->p.max_iterations;
+  uint32_t launches = max_iter > 0 ? max_iter : 1000; /* reference: 0 = until convergence (LieGaussNewton.cpp:27) */
+  CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
+  for (uint32_t i = 0; i < launches; ++i)
+    CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
+                            (double)c->p.delta, 0, with_history));
+  return SUMA_OK;
+}
+
+extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[16], double* history,
+                                 uint32_t history_cap, uint32_t* n_hist, suma_icp_stats* stats) {
+  if (!c || !T0 || !T_out) return SUMA_ERR_INVALID;
+  if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
+  const int with_history = (history != nullptr && history_cap > 0) ? 1 : 0;
+  int r = enqueue_minimize(c, T0, 1, with_history);
+  if (r) return r;
+  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  const GnState& g = c->h_gn[0];
+  memcpy(T_out, g.Tk, sizeof(g.Tk));
+  fill_stats(g, stats);
+  if (n_hist) *n_hist = g.n_hist;
+  if (with_history) {
+    uint32_t n = g.n_hist < history_cap ? g.n_hist : history_cap;
+    if (n > c->gn_history_cap) n = c->gn_history_cap;
+    CK(hipMemcpyAsync(history, c->gn_history, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream));
+  }
+  return SUMA_OK;
+}
+
+extern "C" int suma_icp_minimize_batch(suma_ctx* c, const double* T0s, uint32_t n_hyp, double* T_out,
+                                       suma_icp_stats* stats) {
+  if (!c || !T0s || !T_out || n_hyp == 0 || n_hyp > SUMA_MAX_HYP) return SUMA_ERR_INVALID;
+  if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
+  int r = enqueue_minimize(c, T0s, n_hyp, 0);
+  if (r) return r;
+  CK(hipMemcpyAsync(c->h_gn, c->gn, (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  for (uint32_t h = 0; h < n_hyp; ++h) {
+    memcpy(T_out + 16 * (size_t)h, c->h_gn[h].Tk, 16 * sizeof(double));
+    if (stats) fill_stats(c->h_gn[h], &stats[h]);
+  }
+  return SUMA_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * SurfelMap
+ * ------------------------------------------------------------------------------------------- */
+extern "C" int suma_map_reset(suma_ctx* c) {
+  if (!c) return SUMA_ERR_INVALID;
+  return map_reset_impl(c);
+}
+
+static void submap_center(const suma_ctx* c, int32_t i, int32_t j, float* cx, float* cy) {
+  *cx = (float)(2.0 * i * c->p.submap_extent); /* SurfelMap.cpp:704-706 */
+  *cy = (float)(2.0 * j * c->p.submap_extent);
+}
+
+static int cache_slot_for(suma_ctx* c, int32_t i, int32_t j, uint32_t* slot) {
+  auto key = std::make_pair(i, j);
+  auto it = c->cache_index.find(key);
+  if (it != c->cache_index.end()) {
+    *slot = it->second;
+    return SUMA_OK;
+  }
+  uint32_t s = (uint32_t)c->cache_index.size();
+  if (s >= c->cache_slots_cap) return fail(c, SUMA_ERR_CAPACITY, "submap cache slot table exhausted");
+  c->cache_index[key] = s;
+  *slot = s;
+  return SUMA_OK;
+}
+
+/* SurfelMap::extractSurfels, SurfelMap.cpp:708-742 (tiles are popped from the back) */
+static int extract_surfels(suma_ctx* c, bool partially) {
+  while (!c->extraction.empty()) {
+    auto idx = c->extraction.back();
+    c->extraction.pop_back();
+    float cx, cy;
+    submap_center(c, idx.first, idx.second, &cx, &cy);
+    uint32_t slot;
+    int r = cache_slot_for(c, idx.first, idx.second, &slot);
+    if (r) return r;
+    CK(launch_extract(c, slot, cx, cy, c->p.submap_extent));
+    if (partially) break;
+  }
+  return SUMA_OK;
+}
+
+static int append_cached(suma_ctx* c, int32_t i, int32_t j) {
+  auto it = c->cache_index.find(std::make_pair(i, j));
+  if (it == c->cache_index.end()) return SUMA_OK; /* never extracted: an empty SubmapCache */
+  CK(launch_append_cached(c, it->second));
+  return SUMA_OK;
+}
+
+/* SurfelMap::updateActiveSubmaps, SurfelMap.cpp:744-824 */
+static int update_active_submaps(suma_ctx* c, const float* pose) {
+  const int32_t dim = c->p.submap_dimension;
+  const float ext = c->p.submap_extent;
+  float cx, cy;
+  submap_center(c, c->origin_i, c->origin_j, &cx, &cy);
+  float changex = pose[12] - cx, changey = pose[13] - cy;
+  const float factor = 1.1f;
+  if (fabsf(changex) > factor * ext || fabsf(changey) > factor * ext) {
+    if (fabsf(changex) > factor * ext) {
+      int32_t dir = (changex < 0) ? -1 : 1;
+      for (int32_t k = -dim; k <= dim; ++k) c->extraction.push_back({c->origin_i - dir * dim, c->origin_j + k});
+      c->origin_i += dir;
+      for (int32_t k = -dim; k <= dim; ++k) {
+        int r = append_cached(c, c->origin_i + dir * dim, c->origin_j + k);
+        if (r) return r;
+      }
+    }
+    if (fabsf(changey) > factor * ext) {
+      int32_t dir = (changey < 0) ? -1 : 1;
+      for (int32_t r0 = -dim; r0 <= dim; ++r0) c->extraction.push_back({c->origin_i + r0, c->origin_j - dir * dim});
+      c->origin_j += dir;
+      for (int32_t r0 = -dim; r0 <= dim; ++r0) {
+        int r = append_cached(c, c->origin_i + r0, c->origin_j + dir * dim);
+        if (r) return r;
+      }
+    }
+  }
+  if (!c->extraction.empty()) return extract_surfels(c, c->p.partial_extraction != 0);
+  return SUMA_OK;
+}
+
+extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_frame* frame) {
+  if (!c || !pose || !frame) return SUMA_ERR_INVALID;
+  if (frame->width != c->p.data_width || frame->height != c->p.data_height)
+    return fail(c, SUMA_ERR_INVALID, "suma_map_update: frame size differs from data_width x data_height");
+  if (c->timestamp >= c->p.max_poses)
+    return fail(c, SUMA_ERR_CAPACITY, "pose table full (max_poses; reference: maxPoses_ = 10000, SurfelMap.h:205)");
+  CK(launch_set_pose(c, c->timestamp, pose)); /* SurfelMap.cpp:494-495 */
+  float inv_pose[16];
+  rigid_inverse_f(pose, inv_pose);
+  /* K11 area, SurfelMap.cpp:667-677 */
+  float cx, cy;
+  submap_center(c, c->origin_i, c->origin_j, &cx, &cy);
+  float extent = 2.0f * (float)c->p.submap_dimension * c->p.submap_extent + c->p.submap_extent;
+  if (c->p.partial_extraction && !c->extraction.empty()) extent += 2.0f * c->p.submap_extent;
+  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent));
+  c->cur ^= 1;
+  int r = update_active_submaps(c, pose);
+  if (r) return r;
+  c->timestamp += 1;
+  return SUMA_OK;
+}
+
+extern "C" int suma_map_render(suma_ctx* c, const float pose_old[16], const float pose_new[16], float conf_threshold,
+                               suma_frame* out) {
+  if (!c || !pose_old || !pose_new || !out) return SUMA_ERR_INVALID;
+  if (out->width != c->p.model_width || out->height != c->p.model_height)
+    return fail(c, SUMA_ERR_INVALID, "suma_map_render: frame size differs from model_width x model_height");
+  CK(launch_map_render(c, pose_old, pose_new, conf_threshold, out));
+  return SUMA_OK;
+}
+extern "C" int suma_map_render_active(suma_ctx* c, const float pose[16], float conf_threshold) {
+  if (!c || !pose) return SUMA_ERR_INVALID;
+  CK(launch_map_render_single(c, pose, conf_threshold, 1));
+  return SUMA_OK;
+}
+extern "C" int suma_map_render_inactive(suma_ctx* c, const float pose[16], float conf_threshold) {
+  if (!c || !pose) return SUMA_ERR_INVALID;
+  CK(launch_map_render_single(c, pose, conf_threshold, 0));
+  return SUMA_OK;
+}
+extern "C" int suma_map_render_composed(suma_ctx* c, const float pose_old[16], const float pose_new[16],
+                                        float conf_threshold) {
+  if (!c || !pose_old || !pose_new) return SUMA_ERR_INVALID;
+  CK(launch_map_render_composed(c, pose_old, pose_new, conf_threshold));
+  return SUMA_OK;
+}
+extern "C" suma_frame* suma_map_frame(suma_ctx* c, int which) {
+  if (!c) return nullptr;
+  return which == SUMA_FRAME_OLD ? c->old_frame : (which == SUMA_FRAME_NEW ? c->new_frame : c->composed_frame);
+}
+
+extern "C" int suma_map_update_poses(suma_ctx* c, const float* poses16, uint32_t n) {
+  if (!c || (!poses16 && n)) return SUMA_ERR_INVALID;
+  if (n > c->p.max_poses) n = c->p.max_poses;
+  if (n == 0) return SUMA_OK;
+  float* d_tmp = nullptr;
+  CK(hipMalloc((void**)&d_tmp, (size_t)n * 16 * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(d_tmp, poses16, (size_t)n * 16 * sizeof(float), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = launch_set_poses(c, d_tmp, 0, n);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  hipFree(d_tmp);
+  CK(e);
+  return SUMA_OK;
+}
+
+static int check_overflow(suma_ctx* c) {
+  if (c->h_ds->overflow & 1u) return fail(c, SUMA_ERR_CAPACITY, "surfel capacity (max_surfels) exceeded; map truncated");
+  if (c->h_ds->overflow & 2u) return fail(c, SUMA_ERR_CAPACITY, "submap cache arena (cache_surfels) exhausted");
+  return SUMA_OK;
+}
+
+extern "C" int suma_map_size(suma_ctx* c, uint32_t* n) {
+  if (!c || !n) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  *n = c->h_ds->n_surfels;
+  return check_overflow(c);
+}
+extern "C" int suma_map_timestamp(suma_ctx* c, uint32_t* t) {
+  if (!c || !t) return SUMA_ERR_INVALID;
+  *t = c->timestamp;
+  return SUMA_OK;
+}
+extern "C" int suma_map_download(suma_ctx* c, suma_surfel* host, uint32_t cap, uint32_t* n) {
+  if (!c) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  uint32_t S = c->h_ds->n_surfels;
+  if (n) *n = S;
+  uint32_t m = S < cap ? S : cap;
+  if (m && host) {
+    CK(hipMemcpyAsync(host, c->surfels[c->cur], (size_t)m * sizeof(suma_surfel), hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream));
+  }
+  return SUMA_OK;
+}
+extern "C" int suma_map_upload(suma_ctx* c, const suma_surfel* host, uint32_t n, uint32_t timestamp) {
+  if (!c || (!host && n)) return SUMA_ERR_INVALID;
+  if (n > c->p.max_surfels) n = c->p.max_surfels;
+  if (n) CK(hipMemcpyAsync(c->surfels[c->cur], host, (size_t)n * sizeof(suma_surfel), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(&c->ds->n_surfels, &n, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  c->timestamp = timestamp;
+  c->known_surfels = n;
+  return SUMA_OK;
+}
+extern "C" int suma_map_download_index_map(suma_ctx* c, uint32_t* host) {
+  if (!c || !host) return SUMA_ERR_INVALID;
+  CK(hipMemcpyAsync(host, c->index_map, c->P * 4, hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" int suma_map_download_radius_conf(suma_ctx* c, suma_float4* host) {
+  if (!c || !host) return SUMA_ERR_INVALID;
+  CK(hipMemcpyAsync(host, c->radius_conf, c->P * sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" int suma_map_download_integrated(suma_ctx* c, uint8_t* host) {
+  if (!c || !host) return SUMA_ERR_INVALID;
+  CK(hipMemcpyAsync(host, c->integrated, c->P, hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+extern "C" int suma_map_counts(suma_ctx* c, uint32_t* n_updated, uint32_t* n_new, uint32_t* n_cached,
+                               int32_t origin_ij[2]) {
+  if (!c) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  if (n_updated) *n_updated = c->h_ds->n_updated;
+  if (n_new) *n_new = c->h_ds->n_data;
+  if (n_cached) {
+    uint32_t ns = (uint32_t)c->cache_index.size();
+    std::vector<CacheSlot> slots(ns);
+    if (ns) {
+      CK(hipMemcpyAsync(slots.data(), c->cache_slots, ns * sizeof(CacheSlot), hipMemcpyDeviceToHost, c->stream));
+      CK(hipStreamSynchronize(c->stream));
+    }
+    uint32_t s = 0;
+    for (auto& q : slots) s += q.count;
+    *n_cached = s;
+  }
+  if (origin_ij) {
+    origin_ij[0] = c->origin_i;
+    origin_ij[1] = c->origin_j;
+  }
+  return SUMA_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * SurfelMapping::processScan
+ * ------------------------------------------------------------------------------------------- */
+static void eye_d(double* T) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+}
+static void mul4_d(const double* A, const double* B, double* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      C[4 * c + r] =
+          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+}
+static void rigid_inv_d(const double* m, double* out) {
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) out[4 * c + r] = m[4 * r + c];
+  for (int r = 0; r < 3; ++r) out[12 + r] = -((m[4 * r] * m[12] + m[4 * r + 1] * m[13]) + m[4 * r + 2] * m[14]);
+  out[3] = out[7] = out[11] = 0.0;
+  out[15] = 1.0;
+}
+static void cast_f(const double* T, float* out) {
+  for (int i = 0; i < 16; ++i) out[i] = (float)T[i];
+}
+
+extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, suma_pipeline** out) {
+  if (!params || !out) return SUMA_ERR_INVALID;
+  *out = nullptr;
+  suma_ctx* c = nullptr;
+  int r = suma_ctx_create(params, hip_device, &c);
+  if (r) return r;
+  suma_pipeline* s = new (std::nothrow) suma_pipeline();
+  if (!s) {
+    suma_ctx_destroy(c);
+    return SUMA_ERR_NOMEM;
+  }
+  memset(s, 0, sizeof(*s));
+  s->c = c;
+  suma_frame** fr[4] = {&s->last_frame, &s->current_frame, &s->current_model, &s->last_model};
+  for (int k = 0; k < 4; ++k) {
+    bool data = k < 2;
+    r = frame_create_raw(c, data ? params->data_width : params->model_width,
+                         data ? params->data_height : params->model_height, fr[k]);
+    if (r) {
+      g_create_error = c->err;
+      suma_pipeline_destroy(s);
+      return r;
+    }
+  }
+  eye_d(s->current_pose);
+  eye_d(s->last_pose);
+  eye_d(s->pose_old);
+  eye_d(s->pose_new);
+  eye_d(s->last_increment);
+  float p_unstable = 0.1f; /* SurfelMapping.cpp:108-109 */
+  s->log_unstable = (float)log((double)(p_unstable / (1.0f - p_unstable)));
+  *out = s;
+  return SUMA_OK;
+}
+extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
+  if (!s) return;
+  if (s->c && s->c->stream) hipStreamSynchronize(s->c->stream);
+  suma_frame_destroy(s->last_frame);
+  suma_frame_destroy(s->current_frame);
+  suma_frame_destroy(s->current_model);
+  suma_frame_destroy(s->last_model);
+  suma_ctx_destroy(s->c);
+  delete s;
+}
+extern "C" suma_ctx* suma_pipeline_ctx(suma_pipeline* s) { return s ? s->c : nullptr; }
+extern "C" int suma_pipeline_pose(const suma_pipeline* s, double pose[16]) {
+  if (!s || !pose) return SUMA_ERR_INVALID;
+  memcpy(pose, s->current_pose, 16 * sizeof(double));
+  return SUMA_OK;
+}
+extern "C" int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]) {
+  if (!s || !inc) return SUMA_ERR_INVALID;
+  memcpy(inc, s->last_increment, 16 * sizeof(double));
+  return SUMA_OK;
+}
+extern "C" int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st) {
+  if (!s || !st) return SUMA_ERR_INVALID;
+  *st = s->stats;
+  return SUMA_OK;
+}
+extern "C" uint32_t suma_pipeline_timestamp(const suma_pipeline* s) { return s ? s->timestamp : 0; }
+extern "C" suma_frame* suma_pipeline_frame(suma_pipeline* s, int which) {
+  if (!s) return nullptr;
+  return which == 0 ? s->current_frame : (which == 1 ? s->last_model : s->current_model);
+}
+
+/* SurfelMapping::getConfidenceThreshold, SurfelMapping.cpp:333-340 (time_init = 10) */
+static float conf_threshold(const suma_pipeline* s) {
+  float ct = s->c->p.confidence_threshold;
+  const uint32_t time_init = 10;
+  if (s->timestamp < time_init) {
+    float alpha = (float)s->timestamp / (float)time_init;
+    ct = (float)((1.0 - (double)alpha) * (double)s->log_unstable + (double)(alpha * s->c->p.confidence_threshold));
+  }
+  return ct;
+}
+
+/* one minimisation with the optional fixed-iteration override; reads back pose + stats + counters */
+static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_frame* model, const double* T0, double* T,
+                        int32_t fixed_iterations, suma_icp_stats* st) {
+  suma_ctx* c = s->c;
+  suma_params saved = c->p;
+  if (fixed_iterations > 0) {
+    c->p.max_iterations = (uint32_t)fixed_iterations;
+    c->p.stopping_threshold = 0.0f;
+    c->p.delta = 0.0f;
+  }
+  c->icp_current = cur;
+  c->icp_model = model;
+  int r = enqueue_minimize(c, T0, 1, 0);
+  c->p = saved;
+  if (r) return r;
+  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  c->known_surfels = c->h_ds->n_surfels;
+  memcpy(T, c->h_gn[0].Tk, 16 * sizeof(double));
+  fill_stats(c->h_gn[0], st);
+  return check_overflow(c);
+}
+
+/* SurfelMapping::updatePose, SurfelMapping.cpp:372-476 */
+static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
+  suma_ctx* c = s->c;
+  double T0[16], increment[16];
+  if (!c->p.initialize_identity)
+    memcpy(T0, s->last_increment, sizeof(T0));
+  else
+    eye_d(T0);
+  suma_icp_stats mst;
+  int r = minimize_cfg(s, s->current_frame, c->new_frame, T0, increment, fixed_iterations, &mst);
+  if (r) return r;
+
+  double inv_last[16], delta[16], posed[16], I[16];
+  float posef[16];
+  rigid_inv_d(s->last_increment, inv_last);
+  mul4_d(inv_last, increment, delta);
+  mul4_d(s->pose_new, increment, posed);
+  cast_f(posed, posef);
+  CK(launch_map_render_single(c, posef, conf_threshold(s), 1));            /* :406 */
+  r = suma_frame_copy(c, s->last_model, c->new_frame);                     /* :407 */
+  if (r) return r;
+  eye_d(I);
+  c->icp_current = s->current_frame;
+  c->icp_model = c->new_frame;
+  CK(launch_gn_init(c, I, 1, 0, 0));
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0)); /* :411-413, statistics only */
+  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+
+  float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
+  float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));
+  float r_err = (float)acos((double)fmaxf(fminf(angle, 1.0f), -1.0f));
+  const bool fallback = (s->timestamp > 1 && (t_err > 0.4f || r_err > 0.1f) && c->p.fallback_mode); /* :438-449 */
+  CK(hipStreamSynchronize(c->stream));
+  suma_icp_stats st;
+  fill_stats(c->h_gn[0], &st);
+  st.iterations = mst.iterations;
+  st.converged = mst.converged;
+  s->stats = st;
+  if (fallback) {
+    s->track_loss += 1;
+    suma_params saved = c->p;
+    c->p.icp_max_distance = c->p.fallback_max_distance;
+    c->p.icp_max_angle = c->p.fallback_max_angle;
+    r = minimize_cfg(s, s->current_frame, s->last_frame, T0, increment, fixed_iterations, &mst);
+    c->p = saved;
+    if (r) return r;
+  }
+  memcpy(s->last_pose, s->current_pose, sizeof(s->last_pose));
+  double np[16];
+  mul4_d(s->current_pose, increment, np);
+  memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->pose_old, np, sizeof(np));
+  memcpy(s->pose_new, np, sizeof(np));
+  memcpy(s->last_increment, increment, sizeof(increment));
+  return SUMA_OK;
+}
+
+extern "C" int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                                                 const float* d_probs, uint32_t n, int32_t fixed_iterations) {
+  if (!s || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
+  suma_ctx* c = s->c;
+  /* initialize(), SurfelMapping.cpp:323-331 */
+  std::swap(s->last_frame, s->current_frame);
+  std::swap(s->last_model, s->current_model);
+  /* preprocess(), :342-358 */
+  int r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
+  if (r) return r;
+  float po[16], pn[16];
+  cast_f(s->pose_old, po);
+  cast_f(s->pose_new, pn);
+  CK(launch_map_render(c, po, pn, conf_threshold(s), s->last_model));
+  if (s->timestamp > 0) {
+    r = update_pose(s, fixed_iterations);
+    if (r) return r;
+  }
+  /* updateMap(), :797-804 */
+  float pc[16];
+  cast_f(s->current_pose, pc);
+  r = suma_map_update(c, pc, s->current_frame);
+  if (r) return r;
+  CK(launch_map_render(c, pc, pc, conf_threshold(s), s->current_model));
+  s->timestamp += 1;
+  return SUMA_OK;
+}
+
+extern "C" int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, const float* labels,
+                                          const float* probs, uint32_t n, int32_t fixed_iterations) {
+  if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
+  int r = stage_scan(s->c, points, labels, probs, n);
+  if (r) return r;
+  return suma_pipeline_process_scan_device(s, (const suma_float4*)s->c->scan_points,
+                                           labels ? s->c->scan_labels : nullptr, probs ? s->c->scan_probs : nullptr, n,
+                                           fixed_iterations);
+}

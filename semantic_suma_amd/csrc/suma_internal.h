@@ -1,0 +1,196 @@
+/*
+ * suma_internal.h -- host-side state of the gfx950 core and the launcher prototypes shared by
+ * the translation units (k_preprocess.hip, k_icp.hip, k_render.hip, k_update.hip, suma_api.hip).
+ */
+#ifndef SUMA_INTERNAL_H_
+#define SUMA_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/suma_hip.h"
+#include "dev_math.h"
+
+#define SUMA_TILE 256u        /* items per compaction tile = threads per block */
+#define SUMA_STREAM_BLOCKS 2048u /* grid of the grid-stride / ticket kernels: 8 blocks per CU */
+#define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
+#define SUMA_MAX_HYP 64u
+
+/* Counters that live in HBM so that no kernel launch needs a host round trip. */
+struct DevState {
+  uint32_t n_surfels;      /* S: size of the active map */
+  uint32_t n_updated;      /* S': survivors of K9 (before the K11 area filter) */
+  uint32_t n_kept_updated; /* survivors of K9 and K11 */
+  uint32_t n_data;         /* D: new surfels emitted by K10 (before the K11 area filter) */
+  uint32_t n_kept_data;
+  uint32_t n_extracted;    /* K12: surfels written by the last extraction */
+  uint32_t overflow;       /* bit 0: surfel capacity, bit 1: cache arena, bit 2: extract capacity */
+  uint32_t ticket;         /* dynamic tile id of the look-back compaction kernels */
+  uint32_t done_blocks;    /* blocks that left the current compaction kernel */
+  uint32_t cache_used;     /* surfels allocated from the submap cache arena */
+  uint32_t pad[6];
+};
+
+/* one cached submap tile in the device arena */
+struct CacheSlot {
+  uint32_t offset, count;
+};
+
+/* Gauss-Newton state of one minimisation, device resident (LieGaussNewton members,
+ * LieGaussNewton.h:56-72, plus Frame2Model's iteration counter and row 7 of its blend target) */
+struct GnState {
+  double Tk[16];
+  double last_error;
+  double F, F_inlier;
+  uint32_t iteration; /* Frame2Model::iteration_ */
+  uint32_t k;         /* LieGaussNewton::k_ */
+  uint32_t done, converged;
+  uint32_t valid, outlier, invalid, n_hist;
+  uint32_t ticket;
+  uint32_t pad[3];
+  int64_t acc[SUMA_ACC_WORDS];
+  double JtJ[36];
+  double Jtr[6];
+};
+
+struct MapConsts {
+  float pixel_size, log_prior, log_unstable, p_unstable;
+  float radconf_angle_thresh, update_angle_thresh;
+};
+
+struct suma_frame {
+  suma_ctx* ctx;
+  uint32_t width, height;
+  float4* map[3]; /* vertex, normal, semantic: one allocation */
+};
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  int id;
+  double bytes;
+};
+
+struct suma_ctx {
+  suma_params p;
+  int device;
+  hipStream_t stream;
+  std::string err;
+
+  proj_t pd, pm; /* data / model projection */
+  MapConsts mc;
+  size_t P, Pm;
+
+  /* preprocessing scratch */
+  unsigned long long* zbuf_data; /* P keys: K1 and K7 */
+  float4* eroded;                /* P */
+  float4* scan_points;           /* staging for host scans */
+  float *scan_labels, *scan_probs;
+  uint32_t scan_cap;
+
+  /* ICP */
+  const suma_frame *icp_current, *icp_model;
+  GnState* gn;        /* SUMA_MAX_HYP states */
+  int64_t* gn_partial; /* SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
+  double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
+  double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
+  uint32_t gn_history_cap;
+  uint32_t icp_blocks;
+  GnState* h_gn; /* pinned */
+
+  /* surfel map */
+  suma_surfel* surfels[2]; /* double buffer: active map / compaction target */
+  int cur;
+  float* poses;     /* max_poses x 16 */
+  float* poses_inv; /* max_poses x 16 */
+  suma_frame *old_frame, *new_frame, *composed_frame;
+  unsigned long long *zbuf_a, *zbuf_b; /* Pm */
+  float4* radius_conf;                 /* P */
+  uint8_t* integrated;                 /* P */
+  uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
+  unsigned long long* tile_status;     /* look-back status words */
+  uint32_t n_tiles_cap;
+  uint32_t epoch;
+  DevState* ds;
+  DevState* h_ds; /* pinned */
+  uint32_t timestamp; /* SurfelMap::timestamp_ (host copy; kernels get it by value) */
+  /* submaps (SurfelMap.cpp:744-824): caches live in a device arena, the index on the host */
+  int32_t origin_i, origin_j;
+  suma_surfel* cache_arena;
+  uint32_t cache_cap;
+  CacheSlot* cache_slots; /* device table */
+  uint32_t cache_slots_cap;
+  std::map<std::pair<int32_t, int32_t>, uint32_t> cache_index; /* (i,j) -> slot */
+  std::vector<std::pair<int32_t, int32_t>> extraction;        /* pending tiles, used as a stack */
+
+  /* profiling */
+  bool profiling;
+  std::vector<ProfEvent> prof_events;
+  std::vector<std::string> prof_names;
+  std::vector<double> prof_ms, prof_bytes;
+  std::vector<uint64_t> prof_launches;
+  uint32_t known_surfels; /* last S read back (for the algorithmic-byte model) */
+};
+
+struct suma_pipeline {
+  suma_ctx* c;
+  suma_frame *last_frame, *current_frame, *current_model, *last_model;
+  double current_pose[16], last_pose[16], pose_old[16], pose_new[16], last_increment[16];
+  uint32_t timestamp;
+  float log_unstable;
+  suma_icp_stats stats;
+  uint32_t track_loss;
+};
+
+#define HIP_TRY(ctx, expr)                                                                       \
+  do {                                                                                           \
+    hipError_t e__ = (expr);                                                                     \
+    if (e__ != hipSuccess) {                                                                     \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                           \
+      return SUMA_ERR_HIP;                                                                       \
+    }                                                                                            \
+  } while (0)
+
+/* profiling scope: brackets the launches of one named kernel with events on the ctx stream */
+int prof_begin(suma_ctx* c, const char* name, double bytes);
+void prof_end(suma_ctx* c, int token);
+struct ProfScope {
+  suma_ctx* c;
+  int tok;
+  ProfScope(suma_ctx* c_, const char* name, double bytes) : c(c_), tok(c_->profiling ? prof_begin(c_, name, bytes) : -1) {}
+  ~ProfScope() {
+    if (tok >= 0) prof_end(c, tok);
+  }
+};
+
+/* ---- launchers (each enqueues on c->stream, returns hipGetLastError()) ---- */
+/* k_preprocess.hip */
+hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_labels, const float* d_probs, uint32_t n,
+                             uint32_t timestamp, suma_frame* out);
+/* k_icp.hip */
+hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0);
+hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
+                                int eval_only, int with_history);
+/* k_render.hip */
+hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
+                             suma_frame* out);
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active);
+hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
+                                      float conf_threshold);
+/* k_update.hip */
+hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
+                             float cy, float extent);
+hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16);
+hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);
+hipError_t launch_fill_identity_poses(suma_ctx* c);
+hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent);
+hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
+
+/* host helper shared by api + pipeline */
+void rigid_inverse_f(const float* m, float* out);
+
+#endif

@@ -43,7 +43,7 @@ class SumaParams(C.Structure):
         ("averaging_scheme", i32), ("update_always", i32),
         ("submap_dimension", i32), ("submap_extent", f32), ("partial_extraction", i32),
         ("max_surfels", u32), ("max_poses", u32),
-        ("label_offset", u32), ("prob_offset", u32),
+        ("label_offset", u32), ("prob_offset", u32), ("cache_surfels", u32),
     ]
 
 
@@ -70,7 +70,7 @@ def default_params(**overrides) -> SumaParams:
         sigma_angle=1.0, sigma_distance=1.0, use_stability=1, active_timestamps=100, max_weight=20.0,
         weighting_scheme=0, averaging_scheme=0, update_always=0,
         submap_dimension=4, submap_extent=10.0, partial_extraction=1,
-        max_surfels=2048 * 2048, max_poses=10000, label_offset=4, prob_offset=5,
+        max_surfels=2048 * 2048, max_poses=10000, label_offset=4, prob_offset=5, cache_surfels=0,
     )
     for k, v in overrides.items():
         if not hasattr(p, k):

@@ -1,0 +1,338 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the hand-written gfx950 path, called through
+the C-ABI (libsuma_hip.so), against the CPU oracle on the same seeded inputs.
+
+Bar (BASELINE.json north_star): bit-exact integer outputs (index map, integration mask, surfel
+counts / order / timestamps); pose delta <= 1e-4 m / 1e-5 rad per ICP iteration.  Because oracle
+and kernels evaluate the same IEEE binary32 operation sequence (include/suma_detmath.h, no FMA
+contraction) and the J^T J sums are exact fixed point, every float output is in fact compared
+BIT FOR BIT here; the tolerances appear only where stated.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal, get_scan
+from semantic_suma_amd.types import params_with_size
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from semantic_suma_amd import core
+    core.lib()  # raises if libsuma_hip.so is missing: no silent fallback
+    return core
+
+
+def frames_equal(hf, of, what):
+    for m, name in enumerate(("vertex", "normal", "semantic")):
+        assert_bit_equal(hf.download(m), of.map(m), f"{what}.{name}")
+
+
+def pose_delta(Ta, Tb):
+    d = np.linalg.inv(Ta) @ Tb
+    t = float(np.linalg.norm(d[:3, 3]))
+    r = float(np.arccos(np.clip(0.5 * (np.trace(d[:3, :3]) - 1.0), -1.0, 1.0)))
+    return t, r
+
+
+@pytest.mark.parametrize("width,semantics", [(900, False), (900, True), (2048, True)])
+def test_preprocess_k1_k3(hip, oracle_lib, width, semantics):
+    p = params_with_size(width)
+    pts, lab, prob, _ = get_scan(0, width, semantics)
+    ctx = hip.Context(p)
+    ora = oracle_lib.Oracle(p)
+    for timestamp in (0, 12):  # < 10 drops dynamic classes (gen_vertexmap.vert:95-102)
+        hf = hip.Frame(ctx, width, 64)
+        hip.Preprocessing(ctx).process(pts, hf, lab, prob, timestamp)
+        of = ora.preprocess(pts, lab, prob, timestamp, ora.frame())
+        frames_equal(hf, of, f"preprocess w={width} t={timestamp}")
+        v = hf.download(0)
+        assert 0.5 < float((v[..., 3] > 0).mean()) <= 1.0  # the synthetic scan fills most of the image
+
+
+def test_preprocess_edge_cases(hip, oracle_lib):
+    p = params_with_size(900)
+    ctx = hip.Context(p)
+    ora = oracle_lib.Oracle(p)
+    # empty scan
+    hf = hip.Frame(ctx, 900, 64)
+    empty = np.zeros((0, 4), dtype=np.float32)
+    hip.Preprocessing(ctx).process(empty, hf, None, None, 0)
+    of = ora.preprocess(empty, None, None, 0, ora.frame())
+    frames_equal(hf, of, "empty scan")
+    assert not hf.download(0).any()
+    assert (hf.download(2)[..., 3] == 1.0).all()  # quirk B-2: invalid pixels carry semantic (0,0,0,1)
+    # degenerate points: origin, out of range, out of FOV, NaN, duplicates competing for one pixel
+    pts = np.array([[0, 0, 0, 1], [1, 0, 0, 1], [100, 0, 0, 1], [0, 0, 5, 1], [np.nan, 1, 1, 1],
+                    [10, 0, 0, 1], [10, 0, 0, 1], [10.0000005, 0, 0, 1], [5, 5, -1, 1], [-7, 0.001, -0.5, 1]],
+                   dtype=np.float32)
+    lab = np.arange(10, dtype=np.float32) * 10
+    prob = np.linspace(0.1, 1.0, 10).astype(np.float32)
+    hip.Preprocessing(ctx).process(pts, hf, lab, prob, 3)
+    of = ora.preprocess(pts, lab, prob, 3, ora.frame())
+    frames_equal(hf, of, "degenerate points")
+    # no semantics: NULL labels / probs
+    pts2, _, _, _ = get_scan(1, 900, False)
+    hip.Preprocessing(ctx).process(pts2, hf, None, None, 20)
+    of = ora.preprocess(pts2, None, None, 20, ora.frame())
+    frames_equal(hf, of, "null labels")
+
+
+def _model_and_data(oracle_lib, p, width, semantics, k_model=0, k_data=1):
+    """oracle-made model frame (rendered from a one-scan map) and data frame"""
+    ora = oracle_lib.Oracle(p)
+    pts0, l0, p0, _ = get_scan(k_model, width, semantics)
+    pts1, l1, p1, _ = get_scan(k_data, width, semantics)
+    f0 = ora.preprocess(pts0, l0, p0, 20, ora.frame())
+    f1 = ora.preprocess(pts1, l1, p1, 21, ora.frame())
+    return ora, f0, f1
+
+
+@pytest.mark.parametrize("width,semantics,weight", [(900, False, 1), (900, True, 1), (900, True, 2), (2048, True, 1)])
+def test_k6_jacobian_products(hip, oracle_lib, width, semantics, weight):
+    p = params_with_size(width, weight_function=weight)
+    ora, f0, f1 = _model_and_data(oracle_lib, p, width, semantics)
+    ctx = hip.Context(p)
+    h0, h1 = hip.Frame(ctx, width, 64), hip.Frame(ctx, width, 64)
+    h0.set(f0.vertex, f0.normal, f0.semantic)
+    h1.set(f1.vertex, f1.normal, f1.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    T = np.eye(4)
+    T[:3, 3] = [1.05, 0.02, 0.0]
+    for iteration in (0, 1):
+        obj.initialize(T)
+        obj._iteration = iteration
+        F, JtJ, Jtr = obj.jacobianProducts()
+        Fo, acc, JtJo, Jtro, st = ora.jacobian_products(f1, f0, T, iteration)
+        np.testing.assert_array_equal(obj.acc, acc)  # exact fixed-point sums
+        assert F == Fo and np.array_equal(JtJ, JtJo) and np.array_equal(Jtr, Jtro)
+        assert (obj.valid(), obj.outlier(), obj.inlier(), obj.invalid()) == (st.valid, st.outlier, st.inlier, st.invalid)
+        assert obj.valid() + obj.invalid() == width * 64
+        assert obj.valid() > 1000
+
+
+def test_k6_nearest_sampling_and_empty(hip, oracle_lib):
+    p = params_with_size(900, bilinear_sampling=0)
+    ora, f0, f1 = _model_and_data(oracle_lib, p, 900, True)
+    ctx = hip.Context(p)
+    h0, h1 = hip.Frame(ctx, 900, 64), hip.Frame(ctx, 900, 64)
+    h0.set(f0.vertex, f0.normal, f0.semantic)
+    h1.set(f1.vertex, f1.normal, f1.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    obj.initialize(np.eye(4))
+    F, JtJ, Jtr = obj.jacobianProducts()
+    Fo, acc, JtJo, Jtro, st = ora.jacobian_products(f1, f0, np.eye(4), 0)
+    np.testing.assert_array_equal(obj.acc, acc)
+    # all-invalid model: nothing associates
+    z = np.zeros((64, 900, 4), dtype=np.float32)
+    h0.set(z, z, z)
+    obj.initialize(np.eye(4))
+    F, JtJ, Jtr = obj.jacobianProducts()
+    assert F == 0.0 and not JtJ.any() and obj.valid() == 0 and obj.invalid() == 900 * 64
+
+
+@pytest.mark.parametrize("width", [900, 2048])
+def test_gauss_newton_minimize(hip, oracle_lib, width):
+    p = params_with_size(width, max_iterations=10)
+    ora, f0, f1 = _model_and_data(oracle_lib, p, width, True)
+    ctx = hip.Context(p)
+    h0, h1 = hip.Frame(ctx, width, 64), hip.Frame(ctx, width, 64)
+    h0.set(f0.vertex, f0.normal, f0.semantic)
+    h1.set(f1.vertex, f1.normal, f1.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    gn = hip.LieGaussNewton(ctx)
+    gn.minimize(obj, np.eye(4))
+    To, hist_o, st = ora.minimize(f1, f0, np.eye(4))
+    assert gn.history().shape == hist_o.shape
+    # north_star bar: <= 1e-4 m / 1e-5 rad per ICP iteration (the implementation is in fact bit-exact)
+    for k in range(hist_o.shape[0]):
+        t, r = pose_delta(gn.history()[k], hist_o[k])
+        assert t <= 1e-4 and r <= 1e-5, f"iteration {k}: {t} m, {r} rad"
+    assert np.array_equal(gn.pose(), To), "final pose differs in bits"
+    assert gn.iterationCount() == st.iterations and gn.stats.converged == st.converged
+    # the scan pair is 1.1 m apart along x: ICP must have moved most of the way
+    assert 0.8 < gn.pose()[0, 3] < 1.4
+
+
+def test_gauss_newton_convergence_and_batch(hip, oracle_lib):
+    p = params_with_size(900)  # default.xml: 33 iterations, eps = delta = 1e-4 -> stops early
+    ora, f0, f1 = _model_and_data(oracle_lib, p, 900, False)
+    ctx = hip.Context(p)
+    h0, h1 = hip.Frame(ctx, 900, 64), hip.Frame(ctx, 900, 64)
+    h0.set(f0.vertex, f0.normal, f0.semantic)
+    h1.set(f1.vertex, f1.normal, f1.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    gn = hip.LieGaussNewton(ctx)
+    rng = np.random.default_rng(1234)
+    T0s = []
+    for k in range(8):  # BASELINE config 3: 8 perturbed starts
+        T = np.eye(4)
+        T[:3, 3] = [1.0, 0, 0]
+        if k:
+            T[:3, 3] += rng.uniform(-0.2, 0.2, 3)
+            a = np.deg2rad(rng.uniform(-2, 2))
+            T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T0s.append(T)
+    Ts, stats = gn.minimize_batch(T0s)
+    for k in range(8):
+        To, _, st = ora.minimize(f1, f0, T0s[k])
+        assert np.array_equal(Ts[k], To), f"hypothesis {k}"
+        assert stats[k]["iterations"] == st.iterations and stats[k]["converged"] == st.converged
+        assert stats[k]["valid"] == st.valid and stats[k]["error"] == st.error
+    gn.minimize(obj, T0s[0])
+    assert np.array_equal(gn.pose(), Ts[0])
+    # loose thresholds: the stopping tests of LieGaussNewton.cpp:64-66 must fire at the same iteration,
+    # and the converged step is still applied (quirk B-4)
+    p2 = params_with_size(900, stopping_threshold=0.5, delta=2e-3)
+    ctx.set_params(p2)
+    ora.set_params(p2)
+    gn.minimize(obj, T0s[0])
+    To, hist_o, st = ora.minimize(f1, f0, T0s[0])
+    assert st.converged == 1 and st.iterations < 33, "test setup: the oracle should converge early"
+    assert np.array_equal(gn.pose(), To) and gn.history().shape == hist_o.shape
+    assert gn.stats.converged == 1 and gn.iterationCount() == st.iterations
+
+
+def _run_maps(hip, oracle_lib, p, width, n_scans, semantics=True, step=1):
+    """drive SurfelMap directly with ground-truth poses; compare every stage after every scan"""
+    ctx = hip.Context(p)
+    ora = oracle_lib.Oracle(p)
+    hmap = hip.SurfelMap(ctx)
+    hpre = hip.Preprocessing(ctx)
+    T_first = None
+    for i in range(n_scans):
+        k = i * step
+        pts, lab, prob, T = get_scan(k, width, semantics)
+        if T_first is None:
+            T_first = T
+        pose = np.linalg.inv(T_first) @ T
+        hf = hip.Frame(ctx, width, 64)
+        hpre.process(pts, hf, lab, prob, i)
+        of = ora.preprocess(pts, lab, prob, i, ora.frame())
+        hmap.update(pose, hf)
+        ora.map_update(pose, of)
+        assert_bit_equal(hmap.radius_conf(), ora.map_radius_conf(), f"scan {i} radius_conf")
+        np.testing.assert_array_equal(hmap.index_map(), ora.map_index_map(), err_msg=f"scan {i} index map")
+        np.testing.assert_array_equal(hmap.integrated(), ora.map_integrated(), err_msg=f"scan {i} integration mask")
+        su, sn, cached, origin = hmap.counts()
+        assert (su, sn) == ora.map_counts(), f"scan {i} (S', D)"
+        assert cached == ora.map_cached_surfels() and origin == ora.map_submap_origin()
+        assert hmap.size() == ora.map_size(), f"scan {i} map size"
+        hs, os_ = hmap.getAllSurfels(), ora.map_surfels()
+        assert hs.tobytes() == os_.tobytes(), f"scan {i}: surfel buffers differ"
+        # render from the new pose
+        ct = -2.0 if i < 3 else 0.0
+        hout = hip.Frame(ctx, p.model_width, p.model_height)
+        oout = ora.frame(model=True)
+        hmap.render(pose, pose, hout, ct)
+        ora.map_render(pose, pose, ct, oout)
+        frames_equal(hout, oout, f"scan {i} render out")
+        frames_equal(hmap.oldMapFrame(), ora.map_frame(0), f"scan {i} old frame")
+        frames_equal(hmap.newMapFrame(), ora.map_frame(1), f"scan {i} new frame")
+    return ctx, ora, hmap
+
+
+def test_surfel_map_update_and_render_900(hip, oracle_lib):
+    _run_maps(hip, oracle_lib, params_with_size(900), 900, 5)
+
+
+def test_surfel_map_update_and_render_2048(hip, oracle_lib):
+    _run_maps(hip, oracle_lib, params_with_size(2048), 2048, 3)
+
+
+def test_surfel_map_render_variants(hip, oracle_lib):
+    p = params_with_size(900)
+    ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 3)
+    pts, lab, prob, T = get_scan(2, 900, True)
+    pose = np.linalg.inv(get_scan(0, 900, True)[3]) @ T
+    pose2 = pose.copy()
+    pose2[:3, 3] += [0.3, -0.1, 0.02]
+    # make some surfels "old": pretend the map is 150 scans further (timestamp threshold = t - 100)
+    surf = hmap.getAllSurfels()
+    hmap.upload(surf, 150)
+    ora.map_upload(surf, 150)
+    hmap.render_active(pose2, -1.0)
+    ora.map_render_active(pose2, -1.0)
+    hmap.render_inactive(pose, -1.0)
+    ora.map_render_inactive(pose, -1.0)
+    hmap.render_composed(pose, pose2, -1.0)
+    ora.map_render_composed(pose, pose2, -1.0)
+    for w, nm in ((0, "old"), (1, "new"), (2, "composed")):
+        hf, of = hmap._frame(w), ora.map_frame(w)
+        assert_bit_equal(hf.download(0), of.map(0), f"{nm}.vertex")
+        assert_bit_equal(hf.download(1), of.map(1), f"{nm}.normal")
+    assert hmap.oldMapFrame().download(0)[..., 3].sum() > 1000  # old surfels were rendered
+    # non-compose mode
+    p2 = params_with_size(900, compose_rendering=0)
+    ctx.set_params(p2)
+    ora.set_params(p2)
+    hout, oout = hip.Frame(ctx, 900, 64), ora.frame(model=True)
+    hmap.render(pose, pose2, hout, -1.0)
+    ora.map_render(pose, pose2, -1.0, oout)
+    frames_equal(hout, oout, "non-compose render")
+
+
+def test_submap_paging(hip, oracle_lib):
+    # fast traverse (5 scans apart = 5.5 m per step) with small submaps so that tiles shift, get
+    # extracted to the cache and come back (SurfelMap.cpp:744-824)
+    p = params_with_size(900, submap_extent=4.0, submap_dimension=2)
+    ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 8, step=5)
+    assert ora.map_submap_origin() != (0, 0)
+    assert ora.map_cached_surfels() > 0
+
+
+@pytest.mark.parametrize("width,n_scans", [(900, 6), (2048, 4)])
+def test_pipeline_process_scan(hip, oracle_lib, width, n_scans):
+    """SurfelMapping::processScan end to end: poses, stats, maps after every scan."""
+    p = params_with_size(width)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for k in range(n_scans):
+        pts, lab, prob, T = get_scan(k, width, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=10)
+        op.process_scan(pts, lab, prob, fixed_iterations=10)
+        t, r = pose_delta(hp.getCurrentPose(), op.pose())
+        assert t <= 1e-4 and r <= 1e-5, f"scan {k}: pose differs by {t} m / {r} rad"
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k}: pose bits"
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"scan {k} stats"
+        assert hp.map.size() == op.ctx.map_size(), f"scan {k} map size"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        for w in (0, 1, 2):
+            frames_equal(hp.frame(w), op.frame(w), f"scan {k} frame {w}")
+    # odometry sanity against the synthetic ground truth (1.1 m per scan)
+    gt = np.linalg.inv(get_scan(0, width, True)[3]) @ get_scan(n_scans - 1, width, True)[3]
+    t, r = pose_delta(hp.getCurrentPose(), gt)
+    assert t < 0.5, f"drift {t} m after {n_scans} scans"
+
+
+def test_pipeline_convergence_mode(hip, oracle_lib):
+    """default.xml stopping tests (no fixed iteration count), no semantics: BASELINE config 1 style"""
+    p = params_with_size(900, max_iterations=10)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for k in range(3):
+        pts, lab, prob, _ = get_scan(k, 900, False)
+        hp.processScan(pts, lab, prob)
+        op.process_scan(pts, lab, prob)
+        assert np.array_equal(hp.getCurrentPose(), op.pose())
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict()
+
+
+def test_error_paths(hip):
+    p = params_with_size(900)
+    ctx = hip.Context(p)
+    f = hip.Frame(ctx, 100, 10)
+    with pytest.raises(hip.SumaError):
+        hip.Preprocessing(ctx).process(np.zeros((4, 4), np.float32), f, None, None, 0)  # wrong frame size
+    with pytest.raises(hip.SumaError):
+        hip.SurfelMap(ctx).update(np.eye(4), f)
+    obj = hip.Frame2Model(ctx)
+    with pytest.raises(hip.SumaError):
+        obj.jacobianProducts()  # setData not called
+    p_bad = params_with_size(1024)
+    with pytest.raises(hip.SumaError):
+        ctx.set_params(p_bad)  # geometry is fixed at creation
