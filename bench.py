@@ -1,0 +1,169 @@
+#!/usr/bin/env python
+"""bench.py -- KITTI-style scans/s of the projective-ICP + surfel-fusion hot path on MI355X.
+
+A step = one scan through SurfelMapping::processScan (K1-K3 preprocessing, model rendering, 10
+Gauss-Newton ICP iterations + the statistics pass, map update K7-K11, post-update rendering) on a
+64x2048 range image with semantic-weighted ICP (BASELINE.json configs[1]); scans are synthetic
+(semantic_suma_amd/synth.py) and already resident in HBM when the timed region starts.
+N > 1 (launched by torch.distributed.run, one process per GPU): every rank runs its own
+independent sequence (sequence sharding, weak scaling) and the poses are gathered once over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- dominant kernel: algorithmic bytes per launch / average launch duration, measured with
+                  HIP events on the ctx stream over the timed region
+  cpu_baseline -- the CPU oracle (a port of the reference path, oracle/) timed on a bounded sample of the
+                  same workload on the host cores (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--icp-iterations", type=int, default=10)
+    ap.add_argument("--cpu-scans", type=int, default=20, help="scans of the CPU-oracle baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--kernels-json", default=os.path.join(ROOT, "gpurun_out", "bench_kernels.json"))
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from semantic_suma_amd import core, synth
+    from semantic_suma_amd.distributed import gather_poses
+    from semantic_suma_amd.types import params_with_size
+
+    W, H, K, Wu = args.width, args.height, args.steps, args.warmup
+    p = params_with_size(W, H)
+    pipe = core.SurfelMapping(p, device=local_rank)
+    ctx = pipe.ctx
+
+    # ---- synthetic sequence of this rank (its own stretch of the trajectory), uploaded to HBM
+    k0 = 400 * rank
+    scans = []
+    t_gen = time.perf_counter()
+    for k in range(Wu + K):
+        pts, lab, prob, _ = synth.generate_scan(k0 + k, n_azimuth=W, height=H)
+        scans.append((ctx.device_array(pts), ctx.device_array(lab), ctx.device_array(prob), pts.shape[0],
+                      (pts, lab, prob) if (rank == 0 and k < args.cpu_scans) else None))
+    t_gen = time.perf_counter() - t_gen
+    n_points = float(np.mean([s[3] for s in scans]))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for k in range(Wu):
+        pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+    if not args.no_kernel_events:
+        ctx.profile(True)
+        ctx.profile_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(Wu, Wu + K):
+        pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+    poses = gather_poses(pipe.getCurrentPose(), device=torch.device("cuda", local_rank)) if world > 1 else None
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        assert poses.shape[0] == world
+
+    kernels = [] if args.no_kernel_events else ctx.profile_get()
+    ctx.profile(False)
+    map_size = pipe.map.size()
+    pose = pipe.getCurrentPose()
+    gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + Wu + K - 1)
+    drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    out = {
+        "metric": "scans_per_sec", "value": world * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K,
+        "warmup": Wu, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-like sequence, {H}x{W} range images, "
+                               f"semantic-weighted ICP ({args.icp_iterations} GN iterations + stats pass) + surfel "
+                               "fusion, one sequence per GPU, scans resident in HBM",
+                   "points_per_scan": round(n_points), "map_surfels_end": map_size, "drift_m": round(drift, 4),
+                   "parallelism": f"sequence-sharded x{world}" if world > 1 else "single GPU",
+                   "kernel_events": not args.no_kernel_events},
+    }
+    if kernels:
+        kernels.sort(key=lambda k: -k["total_ms"])
+        for k in kernels:
+            k["avg_us"] = 1000.0 * k["total_ms"] / max(k["launches"], 1)
+            k["bytes_per_launch"] = k["bytes"] / max(k["launches"], 1)
+            k["gbps"] = k["bytes"] / max(k["total_ms"], 1e-9) / 1e6
+        dom = kernels[0]
+        out["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": dom["gbps"], "peak": HBM_PEAK_GBPS,
+                           "unit": "GB/s", "frac": dom["gbps"] / HBM_PEAK_GBPS, "traffic": None,
+                           "avg_launch_us": dom["avg_us"], "bytes_per_launch": dom["bytes_per_launch"],
+                           "launches": dom["launches"],
+                           "kernel_time_share": dom["total_ms"] / sum(k["total_ms"] for k in kernels)}
+        try:
+            os.makedirs(os.path.dirname(args.kernels_json), exist_ok=True)
+            with open(args.kernels_json, "w") as f:
+                json.dump({"elapsed_s": elapsed, "steps": K, "kernels": kernels}, f, indent=1)
+        except OSError:
+            pass
+        print("kernel".ljust(26) + "launches  avg_us   GB/s(alg)  share", file=sys.stderr)
+        tot = sum(k["total_ms"] for k in kernels)
+        for k in kernels:
+            print(f"{k['name']:<26}{k['launches']:>8}{k['avg_us']:>9.1f}{k['gbps']:>11.1f}{100 * k['total_ms'] / tot:>7.1f}%",
+                  file=sys.stderr)
+        print(f"sum of kernel time {tot:.1f} ms of {1000 * elapsed:.1f} ms wall; scan generation {t_gen:.1f} s",
+              file=sys.stderr)
+
+    # ---- CPU baseline: the oracle (port of the reference path) on the first scans of the same sequence
+    if world == 1 and args.cpu_scans > 0:
+        from oracle import pyoracle
+        op = pyoracle.OraclePipeline(p)
+        n_cpu = min(args.cpu_scans, Wu + K)
+        tc = time.perf_counter()
+        for k in range(n_cpu):
+            pts, lab, prob = scans[k][4]
+            op.process_scan(pts, lab, prob, fixed_iterations=args.icp_iterations)
+        tc = time.perf_counter() - tc
+        out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "scans/s", "cores": 1, "kind": "port",
+                               "sample": f"first {n_cpu} scans of the same {H}x{W} sequence through oracle/ "
+                                         f"(single thread of {os.cpu_count()} host cores)"}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

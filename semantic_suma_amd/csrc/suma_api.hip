@@ -99,7 +99,14 @@ int prof_begin(suma_ctx* c, const char* name, double bytes) {
   ProfEvent ev;
   ev.id = id;
   ev.bytes = bytes;
-  if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return -1;
+  for (hipEvent_t* e : {&ev.a, &ev.b}) { /* events are pooled: creation is not on the per-launch path */
+    if (!c->prof_pool.empty()) {
+      *e = c->prof_pool.back();
+      c->prof_pool.pop_back();
+    } else if (hipEventCreate(e) != hipSuccess) {
+      return -1;
+    }
+  }
   hipEventRecord(ev.a, c->stream);
   c->prof_events.push_back(ev);
   return (int)c->prof_events.size() - 1;
@@ -116,8 +123,8 @@ static void prof_collect(suma_ctx* c) {
       c->prof_bytes[ev.id] += ev.bytes;
       c->prof_launches[ev.id] += 1;
     }
-    hipEventDestroy(ev.a);
-    hipEventDestroy(ev.b);
+    c->prof_pool.push_back(ev.a);
+    c->prof_pool.push_back(ev.b);
   }
   c->prof_events.clear();
 }
@@ -305,6 +312,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.a);
     hipEventDestroy(ev.b);
   }
+  for (auto& e : c->prof_pool) hipEventDestroy(e);
   void* dev[] = {c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,

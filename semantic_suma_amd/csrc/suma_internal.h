@@ -130,6 +130,7 @@ struct suma_ctx {
   /* profiling */
   bool profiling;
   std::vector<ProfEvent> prof_events;
+  std::vector<hipEvent_t> prof_pool;
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms, prof_bytes;
   std::vector<uint64_t> prof_launches;
