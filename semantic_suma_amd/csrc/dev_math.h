@@ -119,10 +119,15 @@ SDEV v3 project01(const proj_t& q, v3 p) {
 }
 
 SDEV float4 f4(float x, float y, float z, float w) { return make_float4(x, y, z, w); }
-/* NEAREST + CLAMP_TO_BORDER texel fetch (border colour 0) */
+/* NEAREST + CLAMP_TO_BORDER texel fetch (border colour 0).  Branch-free on purpose: the load is
+ * issued from a clamped (always valid) address and the border case is a select, so that a group
+ * of fetches (5-point stencil, 4 bilinear taps x 3 maps) is ONE batch of loads in flight instead
+ * of a chain of dependent round trips through exec-masked branches. */
 SDEV float4 texel(const float4* __restrict__ map, int32_t w, int32_t h, int32_t x, int32_t y) {
-  if (x < 0 || y < 0 || x >= w || y >= h) return f4(0.f, 0.f, 0.f, 0.f);
-  return map[(size_t)y * (size_t)w + (size_t)x];
+  const bool inside = (x >= 0) & (y >= 0) & (x < w) & (y < h);
+  const int32_t xc = min(max(x, 0), w - 1), yc = min(max(y, 0), h - 1);
+  const float4 v = map[(size_t)yc * (size_t)w + (size_t)xc];
+  return inside ? v : f4(0.f, 0.f, 0.f, 0.f);
 }
 
 #define SUMA_EMPTY_KEY (~0ull)

@@ -23,9 +23,11 @@
  *     fp64, applies exp(delta) to the pose and evaluates the stopping tests, all in HBM-resident
  *     state: the next iteration is just the next launch, there is no host round trip.
  */
+#include <cstdlib>
+
 #include "suma_internal.h"
 
-#define ICP_THREADS 256
+#define ICP_THREADS 512 /* 8 waves per block, one block per CU: 131072 lanes = one 64x2048 image in flight */
 #define MAGIC_D 6755399441055744.0          /* 1.5 * 2^52 */
 #define MAGIC_BITS 0x4338000000000000ll     /* its bit pattern */
 
@@ -37,6 +39,7 @@ struct IcpArgs {
   float angle_thresh, distance_thresh, factor;
   int32_t weight_function, bilinear;
   uint32_t P;
+  int32_t ablate; /* debug only (SUMA_ICP_ABLATE): 0 = full kernel */
 };
 
 __device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map, int32_t w, int32_t h, float x,
@@ -77,17 +80,23 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int mask) {
  * of its words and trades the other half with its partner, so 32 -> 1 word per lane costs
  * 16+8+4+2+1 exchanges plus one final pairwise add.  Afterwards lane L holds the wave total of
  * word ((L>>5)&1)*16 + ((L>>4)&1)*8 + ((L>>3)&1)*4 + ((L>>2)&1)*2 + ((L>>1)&1). */
-__device__ __forceinline__ long long wave_reduce32(long long (&a)[SUMA_ACC_WORDS], int lane) {
+template <int H, int MASK>
+__device__ __forceinline__ void reduce_stage(long long (&a)[SUMA_ACC_WORDS], int lane) {
+  const bool upper = (lane & MASK) != 0;
 #pragma unroll
-  for (int h = 16, mask = 32; h >= 1; h >>= 1, mask >>= 1) {
-    const bool upper = (lane & mask) != 0;
-#pragma unroll
-    for (int i = 0; i < h; ++i) {
-      long long keep = upper ? a[i + h] : a[i];
-      long long send = upper ? a[i] : a[i + h];
-      a[i] = keep + shfl_xor_ll(send, mask);
-    }
+  for (int i = 0; i < H; ++i) {
+    long long keep = upper ? a[i + H] : a[i];
+    long long send = upper ? a[i] : a[i + H];
+    a[i] = keep + shfl_xor_ll(send, MASK);
   }
+}
+__device__ __forceinline__ long long wave_reduce32(long long (&a)[SUMA_ACC_WORDS], int lane) {
+  /* explicit stages: every index is a compile-time constant, the words stay in VGPRs */
+  reduce_stage<16, 32>(a, lane);
+  reduce_stage<8, 16>(a, lane);
+  reduce_stage<4, 8>(a, lane);
+  reduce_stage<2, 4>(a, lane);
+  reduce_stage<1, 2>(a, lane);
   return a[0] + shfl_xor_ll(a[0], 1);
 }
 __device__ __forceinline__ int word_of_lane(int lane) {
@@ -96,51 +105,51 @@ __device__ __forceinline__ int word_of_lane(int lane) {
 }
 
 /* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64, fixed operation order */
-__device__ void solve6(const double* A, const double* b, double* x) {
+__device__ __forceinline__ void solve6(const double* A, const double* b, double* x) {
   double L[36], D[6], y[6];
-  for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  for (int j = 0; j < 6; ++j) {
+  _Pragma("unroll") for (int i = 0; i < 36; ++i) L[i] = 0.0;
+  _Pragma("unroll") for (int j = 0; j < 6; ++j) {
     double d = A[6 * j + j];
-    for (int k = 0; k < j; ++k) d -= (L[6 * k + j] * L[6 * k + j]) * D[k];
+    _Pragma("unroll") for (int k = 0; k < j; ++k) d -= (L[6 * k + j] * L[6 * k + j]) * D[k];
     D[j] = d;
     L[6 * j + j] = 1.0;
-    for (int i = j + 1; i < 6; ++i) {
+    _Pragma("unroll") for (int i = j + 1; i < 6; ++i) {
       double s = A[6 * j + i];
-      for (int k = 0; k < j; ++k) s -= (L[6 * k + i] * L[6 * k + j]) * D[k];
+      _Pragma("unroll") for (int k = 0; k < j; ++k) s -= (L[6 * k + i] * L[6 * k + j]) * D[k];
       L[6 * j + i] = s / d;
     }
   }
-  for (int i = 0; i < 6; ++i) {
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) {
     double s = -b[i];
-    for (int k = 0; k < i; ++k) s -= L[6 * k + i] * y[k];
+    _Pragma("unroll") for (int k = 0; k < i; ++k) s -= L[6 * k + i] * y[k];
     y[i] = s;
   }
-  for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
-  for (int i = 5; i >= 0; --i) {
+  _Pragma("unroll") for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
+  _Pragma("unroll") for (int i = 5; i >= 0; --i) {
     double s = y[i];
-    for (int k = i + 1; k < 6; ++k) s -= L[6 * i + k] * x[k];
+    _Pragma("unroll") for (int k = i + 1; k < 6; ++k) s -= L[6 * i + k] * x[k];
     x[i] = s;
   }
 }
 
 /* SE3::exp, lie_algebra.cpp:4-34; x = (v, omega); column-major */
-__device__ void se3_exp(const double* x, double* T) {
-  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+__device__ __forceinline__ void se3_exp(const double* x, double* T) {
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
   const double v[3] = {x[0], x[1], x[2]}, o[3] = {x[3], x[4], x[5]};
   double theta = sdm_sqrt_d((o[0] * o[0] + o[1] * o[1]) + o[2] * o[2]);
   if (theta > 1e-10) {
     double K[9] = {0, -o[2], o[1], o[2], 0, -o[0], -o[1], o[0], 0};
     double K2[9];
-    for (int r = 0; r < 3; ++r)
-      for (int cc = 0; cc < 3; ++cc)
+    _Pragma("unroll") for (int r = 0; r < 3; ++r)
+      _Pragma("unroll") for (int cc = 0; cc < 3; ++cc)
         K2[3 * r + cc] = (K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc]) + K[3 * r + 2] * K[6 + cc];
     double alpha = sdm_sin_d(theta) / theta;
     double beta = (1 - sdm_cos_d(theta)) / (theta * theta);
     double gamma = (1.0 - sdm_cos_d(theta)) / (theta * theta);
     double delta = (theta - sdm_sin_d(theta)) / (theta * theta * theta);
-    for (int r = 0; r < 3; ++r) {
+    _Pragma("unroll") for (int r = 0; r < 3; ++r) {
       double t = 0.0;
-      for (int cc = 0; cc < 3; ++cc) {
+      _Pragma("unroll") for (int cc = 0; cc < 3; ++cc) {
         double I = (r == cc) ? 1.0 : 0.0;
         T[4 * cc + r] = (I + alpha * K[3 * r + cc]) + beta * K2[3 * r + cc];
         double Vrc = (I + gamma * K[3 * r + cc]) + delta * K2[3 * r + cc];
@@ -155,9 +164,9 @@ __device__ void se3_exp(const double* x, double* T) {
   }
 }
 
-__device__ void mul4d(const double* A, const double* B, double* C) {
-  for (int c = 0; c < 4; ++c)
-    for (int r = 0; r < 4; ++r)
+__device__ __forceinline__ void mul4d(const double* A, const double* B, double* C) {
+  _Pragma("unroll") for (int c = 0; c < 4; ++c)
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)
       C[4 * c + r] =
           ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
 }
@@ -220,8 +229,10 @@ __global__ void __launch_bounds__(ICP_THREADS)
   for (int i = 0; i < SUMA_ACC_WORDS; ++i) acc[i] = 0;
 
   const float fWm = (float)a.Wm, fHm = (float)a.Hm;
+  if (a.ablate != 1)
   for (uint32_t pix = blockIdx.x * ICP_THREADS + threadIdx.x; pix < a.P; pix += gridDim.x * ICP_THREADS) {
     float4 vd4 = a.Vd[pix], nd4 = a.Nd[pix];
+    const float4 sd4 = a.Sd[pix]; /* issued with the other data loads: one memory round trip less */
     float e_d = vd4.w + nd4.w;
     bool pair = false;
     float4 vm4, nm4, sm4;
@@ -237,24 +248,23 @@ __global__ void __launch_bounds__(ICP_THREADS)
       float iy = (1.0f - ((pitch * SUMA_RAD2DEG_F) + a.fov_up) / a.fov) * fHm;
       bool in_image = (ix >= 0.0f && ix < fWm && iy >= 0.0f && iy < fHm); /* false for NaN */
       if (in_image) {
+        /* all 12 taps are issued together (the semantic taps are only needed for valid pairs, but
+         * fetching them speculatively removes a dependent L2 round trip from every lane) */
         if (a.bilinear) {
           vm4 = bilinear_fetch(a.Vm, a.Wm, a.Hm, ix, iy);
           nm4 = bilinear_fetch(a.Nm, a.Wm, a.Hm, ix, iy);
+          sm4 = bilinear_fetch(a.Sm, a.Wm, a.Hm, ix, iy);
         } else {
           int32_t tx = (int32_t)sdm_floor(ix), ty = (int32_t)sdm_floor(iy);
           vm4 = texel(a.Vm, a.Wm, a.Hm, tx, ty);
           nm4 = texel(a.Nm, a.Wm, a.Hm, tx, ty);
+          sm4 = texel(a.Sm, a.Wm, a.Hm, tx, ty);
         }
         float e_m = vm4.w + nm4.w;
-        if (e_m > 1.5f) {
-          pair = true;
-          if (a.bilinear)
-            sm4 = bilinear_fetch(a.Sm, a.Wm, a.Hm, ix, iy);
-          else
-            sm4 = texel(a.Sm, a.Wm, a.Hm, (int32_t)sdm_floor(ix), (int32_t)sdm_floor(iy));
-        }
+        pair = e_m > 1.5f;
       }
     }
+    if (a.ablate == 2) { acc[31] += (long long)(vm4.x + nm4.x + sm4.x + sd4.x); continue; }
     if (pair) {
       v3 v_m = xyz(vm4), n_m = xyz(nm4);
       bool inlier = true;
@@ -275,7 +285,6 @@ __global__ void __launch_bounds__(ICP_THREADS)
         }
       }
       /* semantic weighting, .geom:143-158 */
-      float4 sd4 = a.Sd[pix];
       float data_label = sd4.x * 255.0f, data_prob = sd4.w;
       float model_label = sm4.x * 255.0f;
       if (is_dynamic_label(model_label)) {
@@ -287,7 +296,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
       float wr2 = (weight * residual) * residual;
       acc[27] += fix_bits(wr2);
       acc[29] += 1;
-      if (inlier) {
+      if (inlier && a.ablate != 6) {
         const float J[6] = {n_m.x, n_m.y, n_m.z, cp.x, cp.y, cp.z};
         int k = 0;
 #pragma unroll
@@ -310,7 +319,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
 
   /* wave butterfly -> LDS -> block partial */
   __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
-  __shared__ long long s_tot[8][SUMA_ACC_WORDS];
+  __shared__ long long s_tot[ICP_THREADS / 32][SUMA_ACC_WORDS];
   __shared__ int s_last;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long tot = wave_reduce32(acc, lane);
@@ -331,14 +340,27 @@ __global__ void __launch_bounds__(ICP_THREADS)
     s_last = (t == gridDim.x - 1) ? 1 : 0;
   }
   __syncthreads();
-  if (!s_last) return;
+  if (!s_last || a.ablate == 3) return;
 
   /* ---- last block: total, solve, pose update ---- */
-  {
-    const int word = threadIdx.x & 31, grp = threadIdx.x >> 5; /* 8 groups of 32 words */
+  if (a.ablate != 5) {
+    /* 16 groups of 32 words; the partials sit in other XCDs' L2 / HBM, so every lane issues all of
+     * its (independent) loads before summing: one memory round trip for the whole table */
+    const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    constexpr int G = ICP_THREADS / 32;
     long long s = 0;
-    for (uint32_t b = grp; b < gridDim.x; b += 8)
-      s += __hip_atomic_load(&partial[(size_t)b * SUMA_ACC_WORDS + word], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (uint32_t b0 = grp; b0 < gridDim.x; b0 += G * 16) {
+      long long v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        uint32_t b = b0 + G * u;
+        v[u] = (b < gridDim.x) ? __hip_atomic_load(&partial[(size_t)b * SUMA_ACC_WORDS + word], __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT)
+                               : 0ll;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) s += v[u];
+    }
     s_tot[grp][word] = s;
   }
   __syncthreads();
@@ -347,7 +369,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
   long long tot_acc[SUMA_ACC_WORDS];
   for (int w = 0; w < SUMA_ACC_WORDS; ++w) {
     long long s = 0;
-    for (int g = 0; g < 8; ++g) s += s_tot[g][w];
+    for (int g = 0; g < ICP_THREADS / 32; ++g) s += s_tot[g][w];
     tot_acc[w] = s;
   }
   const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
@@ -368,9 +390,11 @@ __global__ void __launch_bounds__(ICP_THREADS)
     for (int i = 0; i < 6; ++i) Jtr[i] = (double)tot_acc[21 + i] * inv;
   }
   const double err = (double)tot_acc[27] * inv;
-  for (int w = 0; w < SUMA_ACC_WORDS; ++w) gn->acc[w] = tot_acc[w];
-  for (int i = 0; i < 36; ++i) gn->JtJ[i] = JtJ[i];
-  for (int i = 0; i < 6; ++i) gn->Jtr[i] = Jtr[i];
+  if (eval_only) { /* Objective::jacobianProducts outputs; the GN loop keeps them in registers */
+    for (int w = 0; w < SUMA_ACC_WORDS; ++w) gn->acc[w] = tot_acc[w];
+    for (int i = 0; i < 36; ++i) gn->JtJ[i] = JtJ[i];
+    for (int i = 0; i < 6; ++i) gn->Jtr[i] = Jtr[i];
+  }
   gn->F = err;
   gn->F_inlier = (double)tot_acc[28] * inv;
   gn->valid = (uint32_t)n_valid;
@@ -379,8 +403,8 @@ __global__ void __launch_bounds__(ICP_THREADS)
   gn->ticket = 0; /* re-armed for the next launch (kernel boundary orders it) */
   if (eval_only) return;
 
-  double dx[6];
-  solve6(JtJ, Jtr, dx);
+  double dx[6] = {1e-3, 0, 0, 0, 0, 1e-3};
+  if (a.ablate != 4) solve6(JtJ, Jtr, dx);
   int result = 1;
   double linf = 0.0, maxc = Jtr[0];
   for (int i = 0; i < 6; ++i) {
@@ -395,8 +419,12 @@ __global__ void __launch_bounds__(ICP_THREADS)
   if (err < last_error && (de < 0 ? -de : de) < epsilon) result = 0;                  /* :66 */
   double E[16], Tk[16], Tn[16];
   for (int i = 0; i < 16; ++i) Tk[i] = gn->Tk[i];
-  se3_exp(dx, E);
-  mul4d(E, Tk, Tn); /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
+  if (a.ablate != 4) {
+    se3_exp(dx, E);
+    mul4d(E, Tk, Tn);
+  } else {
+    for (int i = 0; i < 16; ++i) Tn[i] = Tk[i] + dx[i % 6];
+  } /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
   for (int i = 0; i < 16; ++i) gn->Tk[i] = Tn[i];
   gn->iteration = iteration + 1;
   gn->last_error = err;
@@ -436,6 +464,10 @@ static IcpArgs make_args(suma_ctx* c) {
   a.weight_function = c->p.weight_function;
   a.bilinear = c->p.bilinear_sampling;
   a.P = (uint32_t)a.W * (uint32_t)a.H;
+  {
+    const char* e = getenv("SUMA_ICP_ABLATE");
+    a.ablate = e ? atoi(e) : 0;
+  }
   return a;
 }
 
