@@ -50,17 +50,18 @@ struct RenderArgs {
 };
 
 struct rvtx {
-  long long X, Y; /* window coordinates in 1/256 pixel */
+  int32_t X, Y; /* window coordinates in 1/256 pixel (|X| < 2^21: 20 bits of image + seam unwrap) */
   float z, tu, tv;
 };
 
-__device__ __forceinline__ long long edge_fn(const rvtx& a, const rvtx& b, long long px, long long py) {
-  return (b.X - a.X) * (py - a.Y) - (b.Y - a.Y) * (px - a.X);
+/* edge function of the directed edge a->b at point (px, py), exact in 64-bit integers */
+__device__ __forceinline__ long long edge_fn(const rvtx& a, const rvtx& b, int32_t px, int32_t py) {
+  return (long long)(b.X - a.X) * (long long)(py - a.Y) - (long long)(b.Y - a.Y) * (long long)(px - a.X);
 }
 /* ownership of a pixel centre exactly on an edge: antisymmetric in the edge direction, so a
  * pixel on the diagonal shared by the two strip triangles is produced exactly once */
 __device__ __forceinline__ bool owns_edge(const rvtx& s, const rvtx& t) {
-  long long dx = t.X - s.X, dy = t.Y - s.Y;
+  int32_t dx = t.X - s.X, dy = t.Y - s.Y;
   return dy > 0 || (dy == 0 && dx < 0);
 }
 
@@ -73,6 +74,9 @@ __device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t 
   return ((unsigned long long)z24 << 33) | (pass << 32) | (unsigned long long)(0xffffffffu - id);
 }
 
+/* One triangle.  The three edge functions are evaluated once at the first pixel centre of the
+ * bounding box and then stepped with 64-bit adds (exact: the same integers as a fresh evaluation),
+ * so the inner loop has no multiplies. */
 __device__ void raster_tri(rvtx A, rvtx B, rvtx C, int32_t W, int32_t H, unsigned long long* __restrict__ zbuf,
                            uint32_t id, int tie) {
   long long area = edge_fn(A, B, C.X, C.Y);
@@ -83,32 +87,44 @@ __device__ void raster_tri(rvtx A, rvtx B, rvtx C, int32_t W, int32_t H, unsigne
     C = t;
     area = -area;
   }
-  long long minX = min(A.X, min(B.X, C.X)), maxX = max(A.X, max(B.X, C.X));
-  long long minY = min(A.Y, min(B.Y, C.Y)), maxY = max(A.Y, max(B.Y, C.Y));
-  long long i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* arithmetic shift = floor */
-  long long j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
+  const int32_t minX = min(A.X, min(B.X, C.X)), maxX = max(A.X, max(B.X, C.X));
+  const int32_t minY = min(A.Y, min(B.Y, C.Y)), maxY = max(A.Y, max(B.Y, C.Y));
+  int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* arithmetic shift = floor */
+  int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
   if (i0 < 0) i0 = 0;
   if (j0 < 0) j0 = 0;
   if (i1 > W - 1) i1 = W - 1;
   if (j1 > H - 1) j1 = H - 1;
+  if (i0 > i1 || j0 > j1) return;
   const bool own0 = owns_edge(B, C), own1 = owns_edge(C, A), own2 = owns_edge(A, B);
   const float fa = (float)area;
-  for (long long j = j0; j <= j1; ++j) {
-    for (long long i = i0; i <= i1; ++i) {
-      long long px = 256 * i + 128, py = 256 * j + 128;
-      long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
-      if (!(w0 > 0 || (w0 == 0 && own0))) continue;
-      if (!(w1 > 0 || (w1 == 0 && own1))) continue;
-      if (!(w2 > 0 || (w2 == 0 && own2))) continue;
-      float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
-      float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
-      float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
-      if ((tu * tu + tv * tv) > 1.0f) continue; /* render_surfels.frag:22 */
-      float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
-      if (!(z >= 0.0f && z <= 1.0f)) continue; /* near / far clipping */
-      unsigned long long key = render_key(depth24(z), id, tie);
-      atomicMin(&zbuf[(size_t)j * (size_t)W + (size_t)i], key);
+  const int32_t px0 = 256 * i0 + 128, py0 = 256 * j0 + 128;
+  long long r0 = edge_fn(B, C, px0, py0), r1 = edge_fn(C, A, px0, py0), r2 = edge_fn(A, B, px0, py0);
+  /* d/dx (one pixel = 256 units): -(b.Y - a.Y) * 256 ; d/dy: +(b.X - a.X) * 256 */
+  const long long dx0 = -256ll * (C.Y - B.Y), dx1 = -256ll * (A.Y - C.Y), dx2 = -256ll * (B.Y - A.Y);
+  const long long dy0 = 256ll * (C.X - B.X), dy1 = 256ll * (A.X - C.X), dy2 = 256ll * (B.X - A.X);
+  for (int32_t j = j0; j <= j1; ++j) {
+    long long w0 = r0, w1 = r1, w2 = r2;
+    unsigned long long* row = zbuf + (size_t)j * (size_t)W;
+    for (int32_t i = i0; i <= i1; ++i) {
+      const bool in = (w0 > 0 || (w0 == 0 && own0)) && (w1 > 0 || (w1 == 0 && own1)) && (w2 > 0 || (w2 == 0 && own2));
+      if (in) {
+        float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+        float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
+        float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
+        if (!((tu * tu + tv * tv) > 1.0f)) { /* render_surfels.frag:22 */
+          float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
+          if (z >= 0.0f && z <= 1.0f) /* near / far clipping */
+            atomicMin(&row[i], render_key(depth24(z), id, tie));
+        }
+      }
+      w0 += dx0;
+      w1 += dx1;
+      w2 += dx2;
     }
+    r0 += dy0;
+    r1 += dy1;
+    r2 += dy2;
   }
 }
 
@@ -147,13 +163,15 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a) {
       if (!selected) continue;
       v3 p, n;
       surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
-      v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
-      v3 v = normalize3(cross3(n, u));
+      /* cheap rejections first (back-facing / outside the image); same predicate as
+       * render_surfels.geom:83-92, evaluated before the tangent frame is built */
       float lp = len3(p);
       bool visible = dot3(n, divs3(neg3(p), lp)) > 0.01f;
+      if (!visible) continue;
       v3 pp = project01(a.q, p);
-      if (!(visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f))
-        continue;
+      if (!(pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f)) continue;
+      v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
+      v3 v = normalize3(cross3(n, u));
       v3 ru = scale3(radius, u), rv = scale3(radius, v);
       v3 corner[4];
       corner[0] = sub3(sub3(p, ru), rv);
@@ -170,8 +188,8 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a) {
         if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
         float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
         if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
-        vt[k].X = (long long)sdm_floor(xw * 256.0f + 0.5f);
-        vt[k].Y = (long long)sdm_floor(yw * 256.0f + 0.5f);
+        vt[k].X = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
+        vt[k].Y = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
         vt[k].z = pr.z;
         vt[k].tu = (k & 1) ? 1.0f : -1.0f;
         vt[k].tv = (k & 2) ? 1.0f : -1.0f;

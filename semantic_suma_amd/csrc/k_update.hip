@@ -15,8 +15,8 @@
  * fixed-function pipeline) becomes a single-pass stable compaction: every 256-surfel tile
  * computes its survivors, publishes its count in an 8-byte status word and obtains its output
  * offset by a decoupled look-back over the preceding tiles' words (tile ids handed out by an
- * atomic ticket, so predecessors are always running).  Output order = input order, exactly as
- * transform feedback guarantees.  K11's area filter is evaluated inside K9 / K10, so the map is
+ * atomic ticket, so predecessors are always running; two-level variant, see lookback_prefix).
+ * Output order = input order, exactly as transform feedback guarantees.  K11's area filter is evaluated inside K9 / K10, so the map is
  * read once and written once per scan instead of being copied a second time:
  *   traffic per scan = 64 B * (S + S_new) + the gathered measurement texels.
  * Point splats with depth test (K7, the K9 integration mask) are 64-bit atomicMin / plain
@@ -36,48 +36,49 @@ __device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, uint32_t f
   return ((unsigned long long)epoch << 34) | ((unsigned long long)flag << 32) | value;
 }
 
-/* Called by wave 0 of a block.  Returns the number of selected items in all tiles before `tile`.
- * Status words are single 8-byte granules carrying {epoch, flag, value}: written and read with
- * relaxed agent-scope atomics (write-through / L1-bypassing), no fences needed because payload
- * and flag travel in the same word.  A stale epoch means "not published yet". */
-__device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, uint32_t tile, uint32_t agg,
-                                    uint32_t epoch, int lane) {
-  if (tile == 0) {
-    if (lane == 0)
-      __hip_atomic_store(&status[0], st_pack(epoch, ST_INC, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return 0;
-  }
-  if (lane == 0)
+/* Two-level prefix for the single-pass stable compaction.  Called by wave 0 of a block; returns
+ * the number of selected items in all tiles before `tile`.
+ *
+ * All tiles of a launch run at (nearly) the same time on this chip (2048 resident blocks), so the
+ * classic decoupled look-back degenerates into a serial walk over windows of aggregate-only
+ * predecessors (one L2/fabric round trip per 64 tiles).  Instead every tile publishes its count
+ * twice: as an 8-byte status word {epoch, count} and into the 64-bit accumulator of its GROUP of
+ * 64 tiles ({tiles arrived, sum} updated by one atomic add).  A tile then needs
+ *      sum over complete groups before its own  +  sum over the earlier tiles of its own group,
+ * i.e. ceil(g / 64) + 1 wave-wide loads, all independent and all issued at once; lanes spin only
+ * on words that are not published yet.  Critical path = compute + one publish + one read.
+ * Status words carry the launch epoch (never cleared); group accumulators are cleared by the
+ * finaliser of each launch (block_leaves_last). */
+__device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
+                                    uint32_t tile, uint32_t ntiles, uint32_t agg, uint32_t epoch, int lane) {
+  const uint32_t g = tile >> 6;
+  if (lane == 0) {
     __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  uint32_t running = 0;
-  int64_t base = (int64_t)tile - 1;
-  for (;;) {
-    int64_t idx = base - lane;
-    unsigned long long w;
-    if (idx >= 0) {
-      do {
-        w = __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
-    } else {
-      w = st_pack(epoch, ST_INC, 0); /* virtual tile -1 */
-    }
-    const bool inc = ((w >> 32) & 3ull) == ST_INC;
-    const unsigned long long ball = __ballot(inc);
-    uint32_t v = (uint32_t)(w & 0xffffffffull);
-    if (ball != 0) {
-      const int first = __ffsll((long long)ball) - 1; /* nearest tile with a known inclusive prefix */
-      if (lane > first) v = 0;
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    running += v;
-    if (ball != 0) break;
-    base -= 64;
+    __hip_atomic_fetch_add(&group[g], (1ull << 32) | (unsigned long long)agg, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (lane == 0)
-    __hip_atomic_store(&status[tile], st_pack(epoch, ST_INC, running + agg), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  return running;
+  uint32_t sum = 0;
+  /* complete groups before mine: every group before g holds exactly 64 tiles */
+  for (uint32_t gi = lane; gi < g; gi += 64) {
+    unsigned long long w;
+    do {
+      w = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(w >> 32) != 64u);
+    sum += (uint32_t)(w & 0xffffffffull);
+  }
+  /* earlier tiles of my own group */
+  const uint32_t j = tile & 63u;
+  if ((uint32_t)lane < j) {
+    unsigned long long w;
+    do {
+      w = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
+    sum += (uint32_t)(w & 0xffffffffull);
+  }
+  (void)ntiles;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
+  return sum;
 }
 
 /* block-level stable ranking of a flag: returns the rank of this thread among the block's
@@ -85,7 +86,8 @@ __device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, uin
 struct BlockRank {
   uint32_t rank, total;
 };
-__device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [4] */) {
+#define TILE_WAVES (SUMA_TILE / 64)
+__device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [TILE_WAVES] */) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long ball = __ballot(flag);
   const uint32_t below = __popcll(ball & ((1ull << lane) - 1ull));
@@ -93,7 +95,7 @@ __device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [
   __syncthreads();
   uint32_t off = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
+  for (int w = 0; w < (int)TILE_WAVES; ++w) {
     uint32_t cnt = s_wave[w];
     if (w < wave) off += cnt;
     tot += cnt;
@@ -104,17 +106,18 @@ __device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [
   return r;
 }
 
-/* ticket bookkeeping shared by the compaction kernels: the last block to leave re-arms the
- * ticket and runs the finaliser */
-__device__ __forceinline__ bool block_leaves_last(DevState* ds) {
-  __shared__ int s_is_last;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t d = __hip_atomic_fetch_add(&ds->done_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_is_last = (d == gridDim.x - 1);
-  }
-  __syncthreads();
-  return s_is_last != 0;
+/* Ticket bookkeeping shared by the compaction kernels.  Every block draws tickets until it gets
+ * one >= ntiles; those failing tickets are ntiles .. ntiles + gridDim.x - 1, and a block draws
+ * its failing ticket only after it has finished all of its tiles, so the block that draws the
+ * largest one knows that every other block is done: it re-arms the ticket and clears the group
+ * accumulators the NEXT launch will use (launches alternate between two halves, so words that may
+ * still receive a straggling atomic of this launch are never written here). */
+__device__ __forceinline__ bool is_finaliser(uint32_t failing_ticket, uint32_t ntiles) {
+  return failing_ticket == ntiles + gridDim.x - 1;
+}
+__device__ __forceinline__ void finalise_tickets(DevState* ds, unsigned long long* group_next, uint32_t group_words) {
+  for (uint32_t gi = threadIdx.x; gi < group_words; gi += blockDim.x) group_next[gi] = 0;
+  if (threadIdx.x == 0) ds->ticket = 0;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -158,6 +161,8 @@ struct UpdArgs {
   const float* poses_inv;
   unsigned long long* zbuf; /* data sized: K7 keys */
   unsigned long long* status;
+  unsigned long long *group, *group_next; /* per 64 tiles: {tiles arrived, sum}; this launch / next launch */
+  uint32_t group_words;
   uint32_t epoch;
   const float4 *V, *N, *Sem;
   const float4* radius_conf;
@@ -377,9 +382,9 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
 
 /* K9 (+ K11 predicate): single-pass update with stable compaction.  Tiles of 256 surfels are
  * handed out by ticket; output offset by decoupled look-back. */
-__global__ void __launch_bounds__(256) k9_update(UpdArgs a) {
+__global__ void __launch_bounds__(SUMA_TILE) k9_update(UpdArgs a) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wave_a[4], s_wave_b[4];
+  __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES];
   __shared__ uint32_t s_prefix;
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
@@ -412,9 +417,10 @@ __global__ void __launch_bounds__(256) k9_update(UpdArgs a) {
       if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(kb);
     }
     BlockRank br = block_rank(emit, s_wave_a); /* contains a __syncthreads */
-    if (threadIdx.x == 0) keep_count += s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
+    if (threadIdx.x == 0)
+      for (int w = 0; w < (int)TILE_WAVES; ++w) keep_count += s_wave_b[w];
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();
@@ -429,12 +435,9 @@ __global__ void __launch_bounds__(256) k9_update(UpdArgs a) {
   }
   if (threadIdx.x == 0 && keep_count)
     __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (block_leaves_last(a.ds)) {
-    if (threadIdx.x == 0) {
-      a.ds->ticket = 0;
-      a.ds->done_blocks = 0;
-      if (ntiles == 0) a.ds->n_kept_updated = 0;
-    }
+  if (is_finaliser(s_tile, ntiles)) {
+    finalise_tickets(a.ds, a.group_next, a.group_words);
+    if (threadIdx.x == 0 && ntiles == 0) a.ds->n_kept_updated = 0;
   }
 }
 
@@ -442,9 +445,9 @@ __global__ void __launch_bounds__(256) k9_update(UpdArgs a) {
  * pixels, in the order of vbo_img_coords_ (x-major, SurfelMap.cpp:88-92).  Appends behind the
  * survivors of K9.  Also exports the K7 winners as a uint32 index map and leaves the z-buffer
  * cleared for the next user. */
-__global__ void __launch_bounds__(256) k10_generate(UpdArgs a) {
+__global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wave_a[4], s_wave_b[4];
+  __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES];
   __shared__ uint32_t s_prefix;
   const int32_t W = a.q.W, H = a.q.H;
   const uint32_t P = (uint32_t)W * (uint32_t)H;
@@ -493,9 +496,10 @@ __global__ void __launch_bounds__(256) k10_generate(UpdArgs a) {
       if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(gb);
     }
     BlockRank br = block_rank(emit, s_wave_a);
-    if (threadIdx.x == 0) new_count += s_wave_b[0] + s_wave_b[1] + s_wave_b[2] + s_wave_b[3];
+    if (threadIdx.x == 0)
+      for (int w = 0; w < (int)TILE_WAVES; ++w) new_count += s_wave_b[w];
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();
@@ -516,18 +520,19 @@ __global__ void __launch_bounds__(256) k10_generate(UpdArgs a) {
   }
   if (threadIdx.x == 0 && new_count)
     __hip_atomic_fetch_add(&a.ds->n_data, new_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (block_leaves_last(a.ds)) {
-    if (threadIdx.x == 0) {
-      a.ds->ticket = 0;
-      a.ds->done_blocks = 0;
-    }
-  }
+  if (is_finaliser(s_tile, ntiles)) finalise_tickets(a.ds, a.group_next, a.group_words);
 }
 
 static void set_m4(m4& d, const float* s) {
   for (int i = 0; i < 16; ++i) d.m[i] = s[i];
 }
 
+static uint32_t compact_grid(suma_ctx* c, uint64_t items) {
+  uint64_t blocks = (items + SUMA_TILE - 1) / SUMA_TILE;
+  if (blocks > SUMA_COMPACT_BLOCKS) blocks = SUMA_COMPACT_BLOCKS;
+  if (blocks < 1) blocks = 1;
+  return (uint32_t)blocks;
+}
 static uint32_t stream_grid(suma_ctx* c, uint64_t items) {
   uint64_t blocks = (items + 255) / 256;
   if (blocks > SUMA_STREAM_BLOCKS) blocks = SUMA_STREAM_BLOCKS;
@@ -550,6 +555,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.poses_inv = c->poses_inv;
   a.zbuf = c->zbuf_data;
   a.status = c->tile_status;
+  a.group_words = c->group_words;
   a.V = f->map[SUMA_MAP_VERTEX];
   a.N = f->map[SUMA_MAP_NORMAL];
   a.Sem = f->map[SUMA_MAP_SEMANTIC];
@@ -595,12 +601,16 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   {
     ProfScope ps(c, "k9_update_surfels", 128.0 * S + 16.0 * P);
     a.epoch = ++c->epoch;
-    k9_update<<<gridS, 256, 0, st>>>(a);
+    a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
+    a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
+    k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), SUMA_TILE, 0, st>>>(a);
   }
   {
     ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);
     a.epoch = ++c->epoch;
-    k10_generate<<<stream_grid(c, P), 256, 0, st>>>(a);
+    a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
+    a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
+    k10_generate<<<compact_grid(c, P), SUMA_TILE, 0, st>>>(a);
   }
   return hipGetLastError();
 }
@@ -683,15 +693,17 @@ struct ExtractArgs {
   CacheSlot* slots;
   const float* poses;
   unsigned long long* status;
+  unsigned long long *group, *group_next;
+  uint32_t group_words;
   uint32_t epoch, slot, arena_cap;
   float cx, cy, extent;
 };
 
 /* extract_surfels.vert:46-64: stable compaction of the surfels of one submap tile into the
  * cache arena (capacity SUMA_EXTRACT_CAPACITY per tile, SurfelMap.cpp:279) */
-__global__ void __launch_bounds__(256) k12_extract(ExtractArgs a) {
+__global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
   __shared__ uint32_t s_tile, s_prefix, s_base;
-  __shared__ uint32_t s_wave[4];
+  __shared__ uint32_t s_wave[TILE_WAVES];
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
@@ -718,7 +730,7 @@ __global__ void __launch_bounds__(256) k12_extract(ExtractArgs a) {
     }
     BlockRank br = block_rank(sel, s_wave);
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, tile, br.total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();
@@ -729,10 +741,9 @@ __global__ void __launch_bounds__(256) k12_extract(ExtractArgs a) {
     if (tile == ntiles - 1 && threadIdx.x == 0) a.ds->n_extracted = s_prefix + br.total;
   }
   (void)s_base;
-  if (block_leaves_last(a.ds)) {
+  if (is_finaliser(s_tile, ntiles)) {
+    finalise_tickets(a.ds, a.group_next, a.group_words);
     if (threadIdx.x == 0) {
-      a.ds->ticket = 0;
-      a.ds->done_blocks = 0;
       uint32_t n = (ntiles == 0) ? 0u : a.ds->n_extracted;
       if (n > SUMA_EXTRACT_CAPACITY) {
         n = SUMA_EXTRACT_CAPACITY;
@@ -759,13 +770,16 @@ hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float 
   a.poses = c->poses;
   a.status = c->tile_status;
   a.epoch = ++c->epoch;
+  a.group_words = c->group_words;
+  a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
+  a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
   a.slot = slot;
   a.arena_cap = c->cache_cap;
   a.cx = cx;
   a.cy = cy;
   a.extent = extent;
   ProfScope ps(c, "k12_extract_submap", 64.0 * (double)c->known_surfels);
-  k12_extract<<<stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P), 256, 0, c->stream>>>(a);
+  k12_extract<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), SUMA_TILE, 0, c->stream>>>(a);
   return hipGetLastError();
 }
 

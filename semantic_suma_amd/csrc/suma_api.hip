@@ -263,6 +263,9 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     c->n_tiles_cap = (uint32_t)(((size_t)params->max_surfels + 2 * P) / SUMA_TILE + 2);
     CK(hipMalloc((void**)&c->tile_status, (size_t)c->n_tiles_cap * 8));
     CK(hipMemsetAsync(c->tile_status, 0, (size_t)c->n_tiles_cap * 8, c->stream));
+    c->group_words = c->n_tiles_cap / 64 + 2;
+    CK(hipMalloc((void**)&c->tile_group, (size_t)2 * c->group_words * 8));
+    CK(hipMemsetAsync(c->tile_group, 0, (size_t)2 * c->group_words * 8, c->stream));
     CK(hipMalloc((void**)&c->ds, sizeof(DevState)));
     CK(hipHostMalloc((void**)&c->h_ds, sizeof(DevState), hipHostMallocDefault));
     memset(c->h_ds, 0, sizeof(DevState));
@@ -314,7 +317,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
   void* dev[] = {c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
-                 c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status,
+                 c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
                  c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs};
   for (void* p : dev)

@@ -16,7 +16,8 @@
 #include "../../include/suma_hip.h"
 #include "dev_math.h"
 
-#define SUMA_TILE 256u        /* items per compaction tile = threads per block */
+#define SUMA_TILE 1024u       /* items per compaction tile = threads per block (16 waves) */
+#define SUMA_COMPACT_BLOCKS 512u /* grid of the ticketed compaction kernels: 2 blocks per CU */
 #define SUMA_STREAM_BLOCKS 2048u /* grid of the grid-stride / ticket kernels: 8 blocks per CU */
 #define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
 #define SUMA_MAX_HYP 64u
@@ -113,6 +114,8 @@ struct suma_ctx {
   uint8_t* integrated;                 /* P */
   uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
   unsigned long long* tile_status;     /* look-back status words */
+  unsigned long long* tile_group;      /* 2 x group_words, per 64 tiles: {arrived, sum}; launches alternate halves */
+  uint32_t group_words;
   uint32_t n_tiles_cap;
   uint32_t epoch;
   DevState* ds;
