@@ -24,6 +24,7 @@
  *   - the resolve pass gathers the winning surfel's attributes, applies K5 and leaves the
  *     z-buffers cleared for the next render (no separate clear launch).
  */
+#include <cstdlib>
 #include <cstring>
 
 #include "suma_internal.h"
@@ -47,6 +48,7 @@ struct RenderArgs {
   int use_stability;
   int32_t thr;
   RenderSlot slot[2];
+  int ablate; /* debug only (SUMA_RENDER_ABLATE) */
 };
 
 struct rvtx {
@@ -154,6 +156,7 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a) {
     const float radius = s0.w, confidence = s1.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
+    if (a.ablate == 1) { if (s0.x + s1.x + s2.x == 12345.f) a.slot[0].zbuf[0] = 0; continue; }
     if (a.use_stability && !(confidence > a.conf_threshold)) continue;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
@@ -170,6 +173,7 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a) {
       if (!visible) continue;
       v3 pp = project01(a.q, p);
       if (!(pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f)) continue;
+      if (a.ablate == 2) { if (pp.x == 12345.f) slot.zbuf[0] = 0; continue; }
       v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
       v3 v = normalize3(cross3(n, u));
       v3 ru = scale3(radius, u), rv = scale3(radius, v);
@@ -195,6 +199,7 @@ __global__ void __launch_bounds__(256) k_render(RenderArgs a) {
         vt[k].tv = (k & 2) ? 1.0f : -1.0f;
       }
       if (bad) continue;
+      if (a.ablate == 3) { if (vt[0].X + vt[1].X + vt[2].Y + vt[3].Y == 123456789) slot.zbuf[0] = 0; continue; }
       /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
       raster_tri(vt[0], vt[1], vt[2], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
       raster_tri(vt[2], vt[1], vt[3], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
@@ -300,6 +305,10 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.use_stability = c->p.use_stability;
   a.thr = thr;
   a.slot[0].enabled = a.slot[1].enabled = 0;
+  {
+    const char* e = getenv("SUMA_RENDER_ABLATE");
+    a.ablate = e ? atoi(e) : 0;
+  }
   return a;
 }
 static uint32_t stream_grid(suma_ctx* c) {

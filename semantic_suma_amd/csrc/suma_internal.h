@@ -138,6 +138,17 @@ struct suma_ctx {
   std::vector<double> prof_ms, prof_bytes;
   std::vector<uint64_t> prof_launches;
   uint32_t known_surfels; /* last S read back (for the algorithmic-byte model) */
+
+  /* what the OLD / NEW frames and the last render() target currently hold: lets render() skip a
+   * call that would reproduce them bit for bit (the reference renders the same map from the same
+   * pose at the end of scan t and again at the start of scan t+1, SurfelMapping.cpp:351,803) */
+  uint64_t map_version, params_version;
+  struct {
+    bool valid;
+    float pose_old[16], pose_new[16], conf_threshold;
+    uint64_t map_version, params_version;
+    const suma_frame* out;
+  } rendered;
 };
 
 struct suma_pipeline {
