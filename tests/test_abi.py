@@ -1,0 +1,72 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol include/suma_hip.h declares,
+the ctypes mirrors have the C layouts, and the product path fails loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()  # hipcc cross-compiles gfx950 without a GPU
+    from semantic_suma_amd import core
+    return core
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "suma_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = set(re.findall(r"\b(suma_[a-z0-9_]+)\s*\(", src))
+    return sorted(n for n in names if n not in ("suma_params_default",))
+
+
+def test_every_declared_symbol_is_exported(built):
+    L = C.CDLL(built.LIB_PATH)
+    names = declared_functions()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/suma_hip.h but not exported: {missing}"
+    assert b"gfx950" in C.c_char_p(C.cast(L.suma_version, C.CFUNCTYPE(C.c_char_p))()).value
+
+
+def test_ctypes_layouts_match_c(built, tmp_path):
+    from semantic_suma_amd.core import KernelTime
+    from semantic_suma_amd.types import SURFEL_DTYPE, IcpStats, SumaParams
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "suma_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(suma_params),sizeof(suma_icp_stats),sizeof(suma_surfel),sizeof(suma_kernel_time),"
+                   "offsetof(suma_params,max_surfels),offsetof(suma_params,cache_surfels));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes[0] == C.sizeof(SumaParams) and sizes[1] == C.sizeof(IcpStats)
+    assert sizes[2] == SURFEL_DTYPE.itemsize == 64 and sizes[3] == C.sizeof(KernelTime)
+    assert sizes[4] == SumaParams.max_surfels.offset and sizes[5] == SumaParams.cache_surfels.offset
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the failure path cannot be exercised")
+    from semantic_suma_amd.types import params_with_size
+    with pytest.raises(built.SumaError, match="no HIP device|no CPU fallback"):
+        built.Context(params_with_size(900))
+    with pytest.raises(built.SumaError):
+        built.SurfelMapping(params_with_size(900))
+
+
+def test_product_never_imports_the_oracle():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/"""
+    pkg = os.path.join(ROOT, "semantic_suma_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "pyoracle" not in text and "libsuma_oracle" not in text and "oracle/" not in text, f
+    for f in ("suma_hip.h", "suma_types.h", "suma_detmath.h"):
+        assert "ora_" not in open(os.path.join(ROOT, "include", f)).read()
