@@ -70,3 +70,19 @@ def test_product_never_imports_the_oracle():
                 assert "pyoracle" not in text and "libsuma_oracle" not in text and "oracle/" not in text, f
     for f in ("suma_hip.h", "suma_types.h", "suma_detmath.h"):
         assert "ora_" not in open(os.path.join(ROOT, "include", f)).read()
+
+
+def test_cpp_adapter_compiles_and_links(built, tmp_path):
+    """include/suma_adapter.hpp (the reference-side binding of INTEGRATION.md) compiles as C++11 and links
+    against libsuma_hip.so"""
+    src = tmp_path / "a.cpp"
+    src.write_text('#include "suma_adapter.hpp"\nint main(){ suma_params p; suma_params_default(&p);\n'
+                   ' try { suma_hip::Context c(p, 0); suma_hip::SurfelMap m(c); return (int)m.size(); }\n'
+                   ' catch (const std::runtime_error&) { return 42; } }\n')
+    exe = tmp_path / "a.out"
+    libdir = os.path.dirname(built.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", libdir, "-lsuma_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    import torch
+    rc = subprocess.call([str(exe)])
+    assert rc == (0 if torch.cuda.is_available() else 42)  # throws like the reference when there is no device
