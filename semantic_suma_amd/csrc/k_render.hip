@@ -18,7 +18,8 @@
  *     feeds up to two z-buffers (old / new) at once;
  *   - the triangle rasteriser is explicit: window coordinates snapped to 1/256 pixel, 64-bit
  *     integer edge functions with an antisymmetric tie rule, affine interpolation of depth and
- *     disc coordinates (gl_Position.w = 1 in render_surfels.geom);
+ *     disc coordinates (gl_Position.w = 1 in render_surfels.geom); pixel tests are distributed
+ *     over the wave (see k_render), not looped per surfel;
  *   - the depth test is a 64-bit atomicMin of (depth24 << 32 | surfel id): GL_LESS with in-order
  *     primitives = smaller depth, then lower id;
  *   - the resolve pass gathers the winning surfel's attributes, applies K5 and leaves the
@@ -76,11 +77,11 @@ __device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t 
   return ((unsigned long long)z24 << 33) | (pass << 32) | (unsigned long long)(0xffffffffu - id);
 }
 
-/* One triangle.  The three edge functions are evaluated once at the first pixel centre of the
- * bounding box and then stepped with 64-bit adds (exact: the same integers as a fresh evaluation),
- * so the inner loop has no multiplies. */
-__device__ void raster_tri(rvtx A, rvtx B, rvtx C, int32_t W, int32_t H, unsigned long long* __restrict__ zbuf,
-                           uint32_t id, int tie) {
+/* One triangle at one pixel centre: coverage (top-left style ownership rule), affine interpolation
+ * of depth and disc coordinates, disc + near/far tests, depth-tested write.  Every quantity is a
+ * function of the triangle and the pixel only, so the work can be distributed freely over lanes. */
+__device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, int32_t j, int32_t W,
+                                             unsigned long long* __restrict__ zbuf, uint32_t id, int tie, int ablate = 0) {
   long long area = edge_fn(A, B, C.X, C.Y);
   if (area == 0) return;
   if (area < 0) {
@@ -89,45 +90,21 @@ __device__ void raster_tri(rvtx A, rvtx B, rvtx C, int32_t W, int32_t H, unsigne
     C = t;
     area = -area;
   }
-  const int32_t minX = min(A.X, min(B.X, C.X)), maxX = max(A.X, max(B.X, C.X));
-  const int32_t minY = min(A.Y, min(B.Y, C.Y)), maxY = max(A.Y, max(B.Y, C.Y));
-  int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* arithmetic shift = floor */
-  int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
-  if (i0 < 0) i0 = 0;
-  if (j0 < 0) j0 = 0;
-  if (i1 > W - 1) i1 = W - 1;
-  if (j1 > H - 1) j1 = H - 1;
-  if (i0 > i1 || j0 > j1) return;
-  const bool own0 = owns_edge(B, C), own1 = owns_edge(C, A), own2 = owns_edge(A, B);
+  const int32_t px = 256 * i + 128, py = 256 * j + 128;
+  const long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
+  if (!(w0 > 0 || (w0 == 0 && owns_edge(B, C)))) return;
+  if (!(w1 > 0 || (w1 == 0 && owns_edge(C, A)))) return;
+  if (!(w2 > 0 || (w2 == 0 && owns_edge(A, B)))) return;
   const float fa = (float)area;
-  const int32_t px0 = 256 * i0 + 128, py0 = 256 * j0 + 128;
-  long long r0 = edge_fn(B, C, px0, py0), r1 = edge_fn(C, A, px0, py0), r2 = edge_fn(A, B, px0, py0);
-  /* d/dx (one pixel = 256 units): -(b.Y - a.Y) * 256 ; d/dy: +(b.X - a.X) * 256 */
-  const long long dx0 = -256ll * (C.Y - B.Y), dx1 = -256ll * (A.Y - C.Y), dx2 = -256ll * (B.Y - A.Y);
-  const long long dy0 = 256ll * (C.X - B.X), dy1 = 256ll * (A.X - C.X), dy2 = 256ll * (B.X - A.X);
-  for (int32_t j = j0; j <= j1; ++j) {
-    long long w0 = r0, w1 = r1, w2 = r2;
-    unsigned long long* row = zbuf + (size_t)j * (size_t)W;
-    for (int32_t i = i0; i <= i1; ++i) {
-      const bool in = (w0 > 0 || (w0 == 0 && own0)) && (w1 > 0 || (w1 == 0 && own1)) && (w2 > 0 || (w2 == 0 && own2));
-      if (in) {
-        float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
-        float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
-        float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
-        if (!((tu * tu + tv * tv) > 1.0f)) { /* render_surfels.frag:22 */
-          float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
-          if (z >= 0.0f && z <= 1.0f) /* near / far clipping */
-            atomicMin(&row[i], render_key(depth24(z), id, tie));
-        }
-      }
-      w0 += dx0;
-      w1 += dx1;
-      w2 += dx2;
-    }
-    r0 += dy0;
-    r1 += dy1;
-    r2 += dy2;
-  }
+  float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+  float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
+  float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
+  if ((tu * tu + tv * tv) > 1.0f) return; /* render_surfels.frag:22 */
+  float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
+  if (!(z >= 0.0f && z <= 1.0f)) return; /* near / far clipping */
+  if (ablate == 6) { zbuf[(size_t)j * (size_t)W + (size_t)i] = render_key(depth24(z), id, tie); return; }
+  if (ablate == 7) { unsigned long long k = render_key(depth24(z), id, tie); if (k == 12345) zbuf[0] = k; return; }
+  atomicMin(&zbuf[(size_t)j * (size_t)W + (size_t)i], render_key(depth24(z), id, tie));
 }
 
 /* (inv_pose * surfelPose) * v, render_surfels.vert:44-48 */
@@ -148,61 +125,141 @@ __device__ __forceinline__ void surfel_to_sensor(const float* __restrict__ poses
   *n = m4_dir(M, nrm);
 }
 
-__global__ void __launch_bounds__(256) k_render(RenderArgs a) {
+/* K4.  Phase 1 (lane per surfel): transform, gate, project the four quad corners, clip the
+ * bounding box.  Phase 2 (wave cooperative): the pixel tests of all 64 surfels of the wave are
+ * laid end to end (prefix sum of the box areas) and handed out 64 at a time, so a lane with a large
+ * footprint no longer stalls 63 lanes with empty ones: at 64x2048 the median surfel covers no
+ * pixel centre at all, the mean box is 3.6 tests, but the mean per-wave maximum is 14 -- a
+ * lane-per-surfel raster loop ran 7x longer than the work it contained. */
+#define RENDER_THREADS 256
+__global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
+  __shared__ int32_t s_rec[RENDER_THREADS][16]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, - */
+  __shared__ uint32_t s_incl[RENDER_THREADS];
   const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
-  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
-    const float4 s0 = sf[4 * (size_t)i], s1 = sf[4 * (size_t)i + 1], s2 = sf[4 * (size_t)i + 2];
-    const float radius = s0.w, confidence = s1.w, count = s2.w;
+  const int lane = threadIdx.x & 63;
+  const int wbase = threadIdx.x & ~63;
+  for (uint32_t blk0 = blockIdx.x * RENDER_THREADS; blk0 < S; blk0 += gridDim.x * RENDER_THREADS) {
+    const uint32_t i = blk0 + threadIdx.x;
+    float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
+    bool live = false;
+    if (i < S) {
+      s0 = sf[4 * (size_t)i];
+      s1 = sf[4 * (size_t)i + 1];
+      s2 = sf[4 * (size_t)i + 2];
+      live = !(a.use_stability && !(s1.w > a.conf_threshold));
+    }
+    const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
-    if (a.ablate == 1) { if (s0.x + s1.x + s2.x == 12345.f) a.slot[0].zbuf[0] = 0; continue; }
-    if (a.use_stability && !(confidence > a.conf_threshold)) continue;
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       const RenderSlot& slot = a.slot[sl];
-      if (!slot.enabled) continue;
-      const bool selected = (slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr);
-      if (!selected) continue;
-      v3 p, n;
-      surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
-      /* cheap rejections first (back-facing / outside the image); same predicate as
-       * render_surfels.geom:83-92, evaluated before the tangent frame is built */
-      float lp = len3(p);
-      bool visible = dot3(n, divs3(neg3(p), lp)) > 0.01f;
-      if (!visible) continue;
-      v3 pp = project01(a.q, p);
-      if (!(pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f)) continue;
-      if (a.ablate == 2) { if (pp.x == 12345.f) slot.zbuf[0] = 0; continue; }
-      v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
-      v3 v = normalize3(cross3(n, u));
-      v3 ru = scale3(radius, u), rv = scale3(radius, v);
-      v3 corner[4];
-      corner[0] = sub3(sub3(p, ru), rv);
-      corner[1] = sub3(add3(p, ru), rv);
-      corner[2] = add3(sub3(p, ru), rv);
-      corner[3] = add3(add3(p, ru), rv);
-      rvtx vt[4];
-      bool bad = false;
+      if (!slot.enabled) continue; /* kernel-uniform */
+      /* ---- phase 1 ---- */
+      uint32_t ntests = 0;
+      if (live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr))) {
+        v3 p, n;
+        surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
+        /* cheap rejections first (back-facing / outside the image); same predicate as
+         * render_surfels.geom:83-92, evaluated before the tangent frame is built */
+        float lp = len3(p);
+        bool visible = dot3(n, divs3(neg3(p), lp)) > 0.01f;
+        v3 pp = project01(a.q, p);
+        if (visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f) {
+          v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
+          v3 v = normalize3(cross3(n, u));
+          v3 ru = scale3(radius, u), rv = scale3(radius, v);
+          v3 corner[4];
+          corner[0] = sub3(sub3(p, ru), rv);
+          corner[1] = sub3(add3(p, ru), rv);
+          corner[2] = add3(sub3(p, ru), rv);
+          corner[3] = add3(add3(p, ru), rv);
+          int32_t X[4], Y[4];
+          float Z[4];
+          bool bad = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        v3 pr = project01(a.q, corner[k]);
-        /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
-        if (pp.x - pr.x > 0.5f) pr.x += 1.0f;
-        if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
-        float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
-        if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
-        vt[k].X = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
-        vt[k].Y = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
-        vt[k].z = pr.z;
-        vt[k].tu = (k & 1) ? 1.0f : -1.0f;
-        vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+          for (int k = 0; k < 4; ++k) {
+            v3 pr = project01(a.q, corner[k]);
+            /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
+            if (pp.x - pr.x > 0.5f) pr.x += 1.0f;
+            if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
+            float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
+            if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
+            X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
+            Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
+            Z[k] = pr.z;
+          }
+          if (!bad) {
+            const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
+            const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
+            int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel centres inside the box */
+            int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
+            i0 = max(i0, 0);
+            j0 = max(j0, 0);
+            i1 = min(i1, a.q.W - 1);
+            j1 = min(j1, a.q.H - 1);
+            if (i0 <= i1 && j0 <= j1) {
+              const int32_t w = i1 - i0 + 1;
+              ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
+              int32_t* r = s_rec[threadIdx.x];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                r[k] = X[k];
+                r[4 + k] = Y[k];
+                r[8 + k] = __float_as_int(Z[k]);
+              }
+              r[12] = i0;
+              r[13] = j0;
+              r[14] = w;
+            }
+          }
+        }
       }
-      if (bad) continue;
-      if (a.ablate == 3) { if (vt[0].X + vt[1].X + vt[2].Y + vt[3].Y == 123456789) slot.zbuf[0] = 0; continue; }
-      /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
-      raster_tri(vt[0], vt[1], vt[2], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
-      raster_tri(vt[2], vt[1], vt[3], a.q.W, a.q.H, slot.zbuf, i, slot.tie);
+      /* inclusive prefix of the test counts over the wave */
+      uint32_t incl = ntests;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        uint32_t o = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += o;
+      }
+      const uint32_t total = __shfl(incl, 63, 64);
+      s_incl[threadIdx.x] = incl;
+      __syncthreads(); /* block-uniform: the outer loop bound and the slot flags are uniform */
+      /* ---- phase 2 ---- */
+      for (uint32_t t = lane; t < (a.ablate == 4 ? 0u : total); t += 64) {
+        /* source lane: the first one whose inclusive prefix exceeds t */
+        int lo = 0, hi = 63;
+#pragma unroll
+        for (int it = 0; it < 6; ++it) {
+          int mid = (lo + hi) >> 1;
+          if (s_incl[wbase + mid] > t)
+            hi = mid;
+          else
+            lo = mid + 1;
+        }
+        const int src = lo;
+        const uint32_t excl = src ? s_incl[wbase + src - 1] : 0u;
+        const int32_t* r = s_rec[wbase + src];
+        const uint32_t q = t - excl, w = (uint32_t)r[14];
+        const uint32_t qj = q / w, qi = q - qj * w;
+        const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
+        rvtx vt[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          vt[k].X = r[k];
+          vt[k].Y = r[4 + k];
+          vt[k].z = __int_as_float(r[8 + k]);
+          vt[k].tu = (k & 1) ? 1.0f : -1.0f;
+          vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+        }
+        const uint32_t id = blk0 + (uint32_t)(wbase + src);
+        /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
+        if (a.ablate == 5) { if (pi + pj + vt[3].X == 123456789) slot.zbuf[0] = id; continue; }
+        raster_pixel(vt[0], vt[1], vt[2], pi, pj, a.q.W, slot.zbuf, id, slot.tie, a.ablate);
+        raster_pixel(vt[2], vt[1], vt[3], pi, pj, a.q.W, slot.zbuf, id, slot.tie, a.ablate);
+      }
+      __syncthreads(); /* s_rec / s_incl are reused by the next slot / iteration */
     }
   }
 }
@@ -355,7 +412,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[1].inv_pose, inv_new);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -383,7 +440,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[0].inv_pose, inv_old);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -420,7 +477,7 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   set_m4(a.slot[0].inv_pose, inv);
   {
     ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv);
@@ -458,7 +515,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
   set_m4(a.slot[1].inv_pose, inv_new);
   {
     ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), 256, 0, c->stream>>>(a);
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv_old);
