@@ -49,6 +49,11 @@ struct RenderArgs {
   int use_stability;
   int32_t thr;
   RenderSlot slot[2];
+  /* optional K7 (gen_indexmap.vert:62-81) fused into this pass: the index-map splat of the same
+   * surfels from slot[0]'s pose into the data-sized z-buffer */
+  int k7_enabled;
+  proj_t k7_q;
+  unsigned long long* k7_zbuf;
   int ablate; /* debug only (SUMA_RENDER_ABLATE) */
 };
 
@@ -152,6 +157,21 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
     const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
+    if (a.k7_enabled && i < S) {
+      /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
+      v3 p, n;
+      surfel_to_sensor(a.poses, a.slot[0].inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
+      float lp = len3(p);
+      if (dot3(n, divs3(neg3(p), lp)) > 0.01f) {
+        v3 pr = project01(a.k7_q, p);
+        float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
+        float zn = 2.0f * pr.z - 1.0f;
+        if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
+          unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
+          atomicMin(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
+        }
+      }
+    }
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       const RenderSlot& slot = a.slot[sl];
@@ -362,6 +382,9 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.use_stability = c->p.use_stability;
   a.thr = thr;
   a.slot[0].enabled = a.slot[1].enabled = 0;
+  a.k7_enabled = 0;
+  a.k7_q = c->pd;
+  a.k7_zbuf = c->zbuf_data;
   {
     const char* e = getenv("SUMA_RENDER_ABLATE");
     a.ablate = e ? atoi(e) : 0;
@@ -465,7 +488,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
 /* render_active (which = 1, SurfelMap.cpp:1023-1069) / render_inactive (which = 0, :1071-1114).
  * Only COLOR0 / COLOR1 are re-attached (:1047-1048): the semantic map of the target frame is NOT
  * refreshed by these calls; restated as such. */
-hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active) {
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7) {
   float inv[16];
   rigid_inverse_f(pose, inv);
   int32_t thr = (int32_t)(c->timestamp - 100u);
@@ -475,8 +498,9 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   a.slot[0].tie = TIE_LOW_INDEX;
   a.slot[0].zbuf = c->zbuf_a;
   set_m4(a.slot[0].inv_pose, inv);
+  a.k7_enabled = fuse_k7;
   {
-    ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
+    ProfScope ps(c, fuse_k7 ? "k4k7_render_indexmap" : "k4_render_surfels", 64.0 * (double)c->known_surfels);
     k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
   }
   ResolveArgs r = resolve_args(c);

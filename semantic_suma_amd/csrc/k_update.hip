@@ -543,7 +543,7 @@ static uint32_t stream_grid(suma_ctx* c, uint64_t items) {
 /* K7..K11 of SurfelMap::update for the current map (c->surfels[c->cur]); the result lands in the
  * other buffer, which the caller makes current. */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent) {
+                             float cy, float extent, int k7_done) {
   const uint32_t P = (uint32_t)c->P;
   const double S = (double)c->known_surfels;
   UpdArgs a;
@@ -594,7 +594,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, c->radius_conf, c->integrated, P, c->mc.pixel_size,
                                                 c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds);
   }
-  {
+  if (!k7_done) { /* otherwise the splat was fused into the post-ICP render pass (same pose, same map) */
     ProfScope ps(c, "k7_indexmap", 64.0 * S + 8.0 * P);
     k7_indexmap<<<gridS, 256, 0, st>>>(a);
   }
@@ -664,6 +664,16 @@ __global__ void k_identity_poses(float* poses, float* poses_inv, uint32_t n) {
     poses[16 * (size_t)k + i] = v;
     poses_inv[16 * (size_t)k + i] = v;
   }
+}
+
+__global__ void k_clear_keys(unsigned long long* z, uint32_t n) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) z[i] = SUMA_EMPTY_KEY;
+}
+hipError_t launch_clear_index_zbuf(suma_ctx* c) {
+  uint32_t P = (uint32_t)c->P;
+  k_clear_keys<<<(P + 255) / 256, 256, 0, c->stream>>>(c->zbuf_data, P);
+  return hipGetLastError();
 }
 
 hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16) {

@@ -200,6 +200,7 @@ static int map_reset_impl(suma_ctx* c) {
   c->known_surfels = 0;
   c->map_version++;
   c->rendered.valid = false;
+  c->k7.valid = false;
   return SUMA_OK;
 }
 
@@ -633,7 +634,14 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
   submap_center(c, c->origin_i, c->origin_j, &cx, &cy);
   float extent = 2.0f * (float)c->p.submap_dimension * c->p.submap_extent + c->p.submap_extent;
   if (c->p.partial_extraction && !c->extraction.empty()) extent += 2.0f * c->p.submap_extent;
-  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent));
+  int k7_done = 0;
+  if (c->k7.valid) { /* zbuf_data holds an index-map splat made by the post-ICP render pass */
+    k7_done = (c->k7.map_version == c->map_version && c->k7.params_version == c->params_version &&
+               memcmp(c->k7.pose, pose, 16 * sizeof(float)) == 0 && frame->width == c->p.data_width);
+    if (!k7_done) CK(launch_clear_index_zbuf(c)); /* different pose after all (fallback ICP): redo K7 */
+    c->k7.valid = false;
+  }
+  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done));
   c->cur ^= 1;
   c->map_version++;
   int r = update_active_submaps(c, pose);
@@ -674,13 +682,13 @@ extern "C" int suma_map_render(suma_ctx* c, const float pose_old[16], const floa
 extern "C" int suma_map_render_active(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
   c->rendered.valid = false;
-  CK(launch_map_render_single(c, pose, conf_threshold, 1));
+  CK(launch_map_render_single(c, pose, conf_threshold, 1, 0));
   return SUMA_OK;
 }
 extern "C" int suma_map_render_inactive(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
   c->rendered.valid = false;
-  CK(launch_map_render_single(c, pose, conf_threshold, 0));
+  CK(launch_map_render_single(c, pose, conf_threshold, 0, 0));
   return SUMA_OK;
 }
 extern "C" int suma_map_render_composed(suma_ctx* c, const float pose_old[16], const float pose_new[16],
@@ -937,7 +945,13 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   mul4_d(s->pose_new, increment, posed);
   cast_f(posed, posef);
   c->rendered.valid = false; /* NEW is re-rendered from the ICP pose */
-  CK(launch_map_render_single(c, posef, conf_threshold(s), 1));            /* :406 */
+  /* updateMap() will build the index map (K7) from this very pose unless the fallback ICP changes
+   * it: fuse the splat into this pass over the surfels */
+  CK(launch_map_render_single(c, posef, conf_threshold(s), 1, 1));         /* :406 */
+  c->k7.valid = true;
+  c->k7.map_version = c->map_version;
+  c->k7.params_version = c->params_version;
+  memcpy(c->k7.pose, posef, sizeof(posef));
   r = suma_frame_copy(c, s->last_model, c->new_frame);                     /* :407 */
   if (r) return r;
   eye_d(I);

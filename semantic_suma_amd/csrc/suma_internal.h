@@ -143,6 +143,12 @@ struct suma_ctx {
    * call that would reproduce them bit for bit (the reference renders the same map from the same
    * pose at the end of scan t and again at the start of scan t+1, SurfelMapping.cpp:351,803) */
   uint64_t map_version, params_version;
+  /* K7 splat already in zbuf_data (fused into the post-ICP render pass of the pipeline) */
+  struct {
+    bool valid;
+    float pose[16];
+    uint64_t map_version, params_version;
+  } k7;
   struct {
     bool valid;
     float pose_old[16], pose_new[16], conf_threshold;
@@ -193,12 +199,13 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
 /* k_render.hip */
 hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
                              suma_frame* out);
-hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active);
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7);
 hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
                                       float conf_threshold);
 /* k_update.hip */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent);
+                             float cy, float extent, int k7_done);
+hipError_t launch_clear_index_zbuf(suma_ctx* c);
 hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16);
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);
 hipError_t launch_fill_identity_poses(suma_ctx* c);
