@@ -18,10 +18,14 @@
  *     1.5*2^52 double trick) and summed as int64: exact and order independent, so the result is
  *     bit-identical for any reduction tree (and to the CPU oracle);
  *   - per-lane int64 accumulators -> wave butterfly (halving exchange, 32 shuffles of 64 bit)
- *     -> LDS across the 4 waves -> one 256-byte partial per block, written write-through;
- *   - the last block to arrive (ticket) sums the partials, solves the 6x6 system by LDL^T in
- *     fp64, applies exp(delta) to the pose and evaluates the stopping tests, all in HBM-resident
- *     state: the next iteration is just the next launch, there is no host round trip.
+ *     -> LDS across the 8 waves -> one 256-byte partial per block (plain stores);
+ *   - no in-kernel hand-off at all: the partials of launch j are consumed by the PROLOGUE of
+ *     launch j+1 (kernel boundary = visibility), where every block redundantly sums them, solves
+ *     the 6x6 system by LDL^T in fp64, applies exp(delta) to the pose and evaluates the stopping
+ *     tests while its own data-pixel loads are already in flight.  This removed a store-ack wait,
+ *     a ticket atomic and an L1-bypassing reload from the critical path of every iteration
+ *     (19 -> see profiles/).  State and partials are double buffered by launch parity; block 0
+ *     writes the state.  The next iteration is just the next launch: no host round trip.
  */
 #include <cstdlib>
 
@@ -39,7 +43,6 @@ struct IcpArgs {
   float angle_thresh, distance_thresh, factor;
   int32_t weight_function, bilinear;
   uint32_t P;
-  int32_t ablate; /* debug only (SUMA_ICP_ABLATE): 0 = full kernel */
 };
 
 __device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map, int32_t w, int32_t h, float x,
@@ -186,7 +189,7 @@ __device__ __forceinline__ void gn_reset(GnState* g, int t, uint32_t iteration0)
     g->converged = 0;
     g->valid = g->outlier = g->invalid = 0;
     g->n_hist = 1;
-    g->ticket = 0;
+    g->pending = 0;
   }
 }
 
@@ -210,29 +213,212 @@ __global__ void k_gn_init1(GnState* g, PoseD T0, double* history, uint32_t itera
   gn_reset(g, t, iteration0);
 }
 
-/* One Gauss-Newton iteration (eval_only = 0) or one Frame2Model::jacobianProducts call at the
- * pose / iteration stored in the state (eval_only = 1).  grid = (blocks, n_hyp). */
-__global__ void __launch_bounds__(ICP_THREADS)
-    k_icp_step(IcpArgs a, GnState* __restrict__ gn_all, long long* __restrict__ partial_all, uint32_t max_iter,
-               double epsilon, double delta_thr, int eval_only, double* __restrict__ history, uint32_t history_cap) {
-  GnState* gn = gn_all + blockIdx.y;
-  if (!eval_only && gn->done) return; /* converged / finished earlier: this launch is a no-op */
-  long long* partial = partial_all + (size_t)blockIdx.y * gridDim.x * SUMA_ACC_WORDS;
+struct IterArgs {
+  IcpArgs a;
+  const GnState* gin;  /* state written by the previous launch */
+  GnState* gout;       /* state this launch writes */
+  const long long* pin; /* partials of the previous launch's pixel phase */
+  long long* pout;
+  uint32_t nblocks;    /* blocks of a pixel phase = partial records per hypothesis */
+  uint32_t max_iter;
+  double epsilon, delta_thr;
+  int eval_only; /* Frame2Model::jacobianProducts only: no solve, no pose update */
+  int pixel;     /* 0: consume-only launch (grid.x = 1) */
+  double* history;
+  uint32_t history_cap;
+};
 
+/* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
+ *   prologue: if the previous launch left partial sums (pending), total them, and -- unless this is
+ *             a jacobianProducts-only call -- solve, update the pose, run the stopping tests
+ *             (LieGaussNewton::step, LieGaussNewton.cpp:53-79).  Done by every block on its own
+ *             copy (identical inputs, identical code => identical results); block 0 records it.
+ *   body:     unless finished, the K6 pixel phase at the current pose -> one partial per block. */
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
+  const IcpArgs& a = g.a;
+  const GnState* __restrict__ gin = g.gin + blockIdx.y;
+  GnState* __restrict__ gout = g.gout + blockIdx.y;
+  const bool writer = (blockIdx.x == 0 && threadIdx.x == 0);
+
+  __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
+  __shared__ long long s_tot[ICP_THREADS / 32][SUMA_ACC_WORDS];
+  __shared__ double s_pose[16];
+  __shared__ uint32_t s_flag[4]; /* done, iteration */
+
+  /* wave-uniform state (scalar loads) */
+  const uint32_t done_in = gin->done, pending = gin->pending;
+  uint32_t iteration = gin->iteration;
+  double Tk[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) Tk[i] = gin->Tk[i];
+
+  /* data-frame loads of this lane's first pixel do not depend on the pose: issue them now so that
+   * their latency overlaps the prologue */
+  const uint32_t pix0 = blockIdx.x * ICP_THREADS + threadIdx.x;
+  const bool want_px = g.pixel && !(done_in && !pending);
+  float4 vd4 = f4(0, 0, 0, 0), nd4 = vd4, sd4 = vd4;
+  if (want_px && pix0 < a.P) {
+    vd4 = a.Vd[pix0];
+    nd4 = a.Nd[pix0];
+    sd4 = a.Sd[pix0];
+  }
+
+  uint32_t done = done_in;
+  if (pending) {
+    /* ---- total of the previous launch's partials: one batch of independent loads per lane ---- */
+    const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * g.nblocks * SUMA_ACC_WORDS;
+    {
+      const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;
+      constexpr int G = ICP_THREADS / 32;
+      long long s = 0;
+      for (uint32_t b0 = grp; b0 < g.nblocks; b0 += G * 16) {
+        long long v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          uint32_t b = b0 + G * u;
+          v[u] = (b < g.nblocks) ? pin[(size_t)b * SUMA_ACC_WORDS + word] : 0ll;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += v[u];
+      }
+      s_tot[grp][word] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      long long tot_acc[SUMA_ACC_WORDS];
+#pragma unroll
+      for (int w = 0; w < SUMA_ACC_WORDS; ++w) {
+        long long s = 0;
+#pragma unroll
+        for (int q = 0; q < ICP_THREADS / 32; ++q) s += s_tot[q][w];
+        tot_acc[w] = s;
+      }
+      const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
+#pragma unroll
+      for (int w = 0; w < 27; ++w) tot_acc[w] -= n_inlier * MAGIC_BITS;
+      tot_acc[27] -= n_valid * MAGIC_BITS;
+      tot_acc[28] -= n_inlier * MAGIC_BITS;
+      const double inv = 1.0 / SUMA_ACC_SCALE;
+      double JtJ[36], Jtr[6];
+      {
+        int k = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+          for (int j = i; j < 6; ++j) {
+            double v = (double)tot_acc[k++] * inv;
+            JtJ[6 * j + i] = v;
+            JtJ[6 * i + j] = v;
+          }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Jtr[i] = (double)tot_acc[21 + i] * inv;
+      }
+      const double err = (double)tot_acc[27] * inv;
+      if (writer) {
+        gout->F = err;
+        gout->F_inlier = (double)tot_acc[28] * inv;
+        gout->valid = (uint32_t)n_valid;
+        gout->outlier = (uint32_t)n_outlier;
+        gout->invalid = (uint32_t)tot_acc[31];
+        if (g.eval_only) { /* Objective::jacobianProducts outputs */
+          for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = tot_acc[w];
+          for (int i = 0; i < 36; ++i) gout->JtJ[i] = JtJ[i];
+          for (int i = 0; i < 6; ++i) gout->Jtr[i] = Jtr[i];
+        }
+      }
+      uint32_t k = gin->k, n_hist = gin->n_hist, converged = gin->converged;
+      double last_error = gin->last_error;
+      if (!g.eval_only) {
+        double dx[6];
+        solve6(JtJ, Jtr, dx);
+        int result = 1;
+        double linf = 0.0, maxc = Jtr[0];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          double ad = dx[i] < 0 ? -dx[i] : dx[i];
+          if (ad > linf) linf = ad;
+          if (Jtr[i] > maxc) maxc = Jtr[i];
+        }
+        if (linf < g.delta_thr) result = 0;                                   /* LieGaussNewton.cpp:64 */
+        if ((maxc < 0 ? -maxc : maxc) < g.epsilon) result = 0;                /* :65 (quirk B-4) */
+        double de = err - last_error;
+        if (err < last_error && (de < 0 ? -de : de) < g.epsilon) result = 0;  /* :66 */
+        double E[16], Tn[16];
+        se3_exp(dx, E);
+        mul4d(E, Tk, Tn); /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Tk[i] = Tn[i];
+        iteration += 1;
+        last_error = err;
+        if (result == 0) {
+          converged = 1;
+          done = 1;
+        } else {
+          k += 1;
+          if (writer && g.history != nullptr && blockIdx.y == 0 && n_hist < g.history_cap)
+            for (int i = 0; i < 16; ++i) g.history[16 * (size_t)n_hist + i] = Tn[i];
+          n_hist += 1;
+          if (k >= g.max_iter) done = 1;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s_pose[i] = Tk[i];
+      s_flag[0] = done;
+      s_flag[1] = iteration;
+      if (writer) {
+        for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
+        gout->last_error = last_error;
+        gout->iteration = iteration;
+        gout->k = k;
+        gout->n_hist = n_hist;
+        gout->converged = converged;
+        gout->done = done;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tk[i] = s_pose[i];
+    done = s_flag[0];
+    iteration = s_flag[1];
+  } else if (writer) {
+    /* nothing to consume: carry the state over to the other buffer */
+    for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
+    gout->last_error = gin->last_error;
+    gout->F = gin->F;
+    gout->F_inlier = gin->F_inlier;
+    gout->iteration = iteration;
+    gout->k = gin->k;
+    gout->n_hist = gin->n_hist;
+    gout->converged = gin->converged;
+    gout->done = done_in;
+    gout->valid = gin->valid;
+    gout->outlier = gin->outlier;
+    gout->invalid = gin->invalid;
+    if (done_in)
+      for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = gin->acc[w];
+  }
+
+  if (!g.pixel || (done && !g.eval_only) || (g.eval_only && pending)) {
+    if (writer) gout->pending = 0;
+    return;
+  }
+
+  /* ---- K6 pixel phase at the current pose ---- */
   float T[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) T[i] = (float)gn->Tk[i]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
-  const uint32_t iteration = gn->iteration;
+  for (int i = 0; i < 16; ++i) T[i] = (float)Tk[i]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
 
   long long acc[SUMA_ACC_WORDS];
 #pragma unroll
   for (int i = 0; i < SUMA_ACC_WORDS; ++i) acc[i] = 0;
 
   const float fWm = (float)a.Wm, fHm = (float)a.Hm;
-  if (a.ablate != 1)
-  for (uint32_t pix = blockIdx.x * ICP_THREADS + threadIdx.x; pix < a.P; pix += gridDim.x * ICP_THREADS) {
-    float4 vd4 = a.Vd[pix], nd4 = a.Nd[pix];
-    const float4 sd4 = a.Sd[pix]; /* issued with the other data loads: one memory round trip less */
+  for (uint32_t pix = pix0; pix < a.P; pix += gridDim.x * ICP_THREADS) {
+    if (pix != pix0) {
+      vd4 = a.Vd[pix];
+      nd4 = a.Nd[pix];
+      sd4 = a.Sd[pix];
+    }
     float e_d = vd4.w + nd4.w;
     bool pair = false;
     float4 vm4, nm4, sm4;
@@ -264,7 +450,6 @@ __global__ void __launch_bounds__(ICP_THREADS)
         pair = e_m > 1.5f;
       }
     }
-    if (a.ablate == 2) { acc[31] += (long long)(vm4.x + nm4.x + sm4.x + sd4.x); continue; }
     if (pair) {
       v3 v_m = xyz(vm4), n_m = xyz(nm4);
       bool inlier = true;
@@ -296,7 +481,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
       float wr2 = (weight * residual) * residual;
       acc[27] += fix_bits(wr2);
       acc[29] += 1;
-      if (inlier && a.ablate != 6) {
+      if (inlier) {
         const float J[6] = {n_m.x, n_m.y, n_m.z, cp.x, cp.y, cp.z};
         int k = 0;
 #pragma unroll
@@ -317,10 +502,7 @@ __global__ void __launch_bounds__(ICP_THREADS)
     }
   }
 
-  /* wave butterfly -> LDS -> block partial */
-  __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
-  __shared__ long long s_tot[ICP_THREADS / 32][SUMA_ACC_WORDS];
-  __shared__ int s_last;
+  /* wave butterfly -> LDS -> block partial (plain stores: the next launch reads them) */
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   long long tot = wave_reduce32(acc, lane);
   if ((lane & 1) == 0) s_wave[wave][word_of_lane(lane)] = tot;
@@ -329,117 +511,10 @@ __global__ void __launch_bounds__(ICP_THREADS)
     long long s = 0;
 #pragma unroll
     for (int w = 0; w < ICP_THREADS / 64; ++w) s += s_wave[w][threadIdx.x];
-    /* write-through (agent-scope) store: visible to the last block without an L2 write-back */
-    __hip_atomic_store(&partial[(size_t)blockIdx.x * SUMA_ACC_WORDS + threadIdx.x], s, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
+    long long* pout = g.pout + (size_t)blockIdx.y * g.nblocks * SUMA_ACC_WORDS;
+    pout[(size_t)blockIdx.x * SUMA_ACC_WORDS + threadIdx.x] = s;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t t = __hip_atomic_fetch_add(&gn->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s_last = (t == gridDim.x - 1) ? 1 : 0;
-  }
-  __syncthreads();
-  if (!s_last || a.ablate == 3) return;
-
-  /* ---- last block: total, solve, pose update ---- */
-  if (a.ablate != 5) {
-    /* 16 groups of 32 words; the partials sit in other XCDs' L2 / HBM, so every lane issues all of
-     * its (independent) loads before summing: one memory round trip for the whole table */
-    const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    constexpr int G = ICP_THREADS / 32;
-    long long s = 0;
-    for (uint32_t b0 = grp; b0 < gridDim.x; b0 += G * 16) {
-      long long v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        uint32_t b = b0 + G * u;
-        v[u] = (b < gridDim.x) ? __hip_atomic_load(&partial[(size_t)b * SUMA_ACC_WORDS + word], __ATOMIC_RELAXED,
-                                                    __HIP_MEMORY_SCOPE_AGENT)
-                               : 0ll;
-      }
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += v[u];
-    }
-    s_tot[grp][word] = s;
-  }
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-
-  long long tot_acc[SUMA_ACC_WORDS];
-  for (int w = 0; w < SUMA_ACC_WORDS; ++w) {
-    long long s = 0;
-    for (int g = 0; g < ICP_THREADS / 32; ++g) s += s_tot[g][w];
-    tot_acc[w] = s;
-  }
-  const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
-  for (int w = 0; w < 27; ++w) tot_acc[w] -= n_inlier * MAGIC_BITS;
-  tot_acc[27] -= n_valid * MAGIC_BITS;
-  tot_acc[28] -= n_inlier * MAGIC_BITS;
-
-  const double inv = 1.0 / SUMA_ACC_SCALE;
-  double JtJ[36], Jtr[6];
-  {
-    int k = 0;
-    for (int i = 0; i < 6; ++i)
-      for (int j = i; j < 6; ++j) {
-        double v = (double)tot_acc[k++] * inv;
-        JtJ[6 * j + i] = v;
-        JtJ[6 * i + j] = v;
-      }
-    for (int i = 0; i < 6; ++i) Jtr[i] = (double)tot_acc[21 + i] * inv;
-  }
-  const double err = (double)tot_acc[27] * inv;
-  if (eval_only) { /* Objective::jacobianProducts outputs; the GN loop keeps them in registers */
-    for (int w = 0; w < SUMA_ACC_WORDS; ++w) gn->acc[w] = tot_acc[w];
-    for (int i = 0; i < 36; ++i) gn->JtJ[i] = JtJ[i];
-    for (int i = 0; i < 6; ++i) gn->Jtr[i] = Jtr[i];
-  }
-  gn->F = err;
-  gn->F_inlier = (double)tot_acc[28] * inv;
-  gn->valid = (uint32_t)n_valid;
-  gn->outlier = (uint32_t)n_outlier;
-  gn->invalid = (uint32_t)tot_acc[31];
-  gn->ticket = 0; /* re-armed for the next launch (kernel boundary orders it) */
-  if (eval_only) return;
-
-  double dx[6] = {1e-3, 0, 0, 0, 0, 1e-3};
-  if (a.ablate != 4) solve6(JtJ, Jtr, dx);
-  int result = 1;
-  double linf = 0.0, maxc = Jtr[0];
-  for (int i = 0; i < 6; ++i) {
-    double ad = dx[i] < 0 ? -dx[i] : dx[i];
-    if (ad > linf) linf = ad;
-    if (Jtr[i] > maxc) maxc = Jtr[i];
-  }
-  const double last_error = gn->last_error;
-  if (linf < delta_thr) result = 0;                                                   /* LieGaussNewton.cpp:64 */
-  if ((maxc < 0 ? -maxc : maxc) < epsilon) result = 0;                                /* :65 (quirk B-4) */
-  double de = err - last_error;
-  if (err < last_error && (de < 0 ? -de : de) < epsilon) result = 0;                  /* :66 */
-  double E[16], Tk[16], Tn[16];
-  for (int i = 0; i < 16; ++i) Tk[i] = gn->Tk[i];
-  if (a.ablate != 4) {
-    se3_exp(dx, E);
-    mul4d(E, Tk, Tn);
-  } else {
-    for (int i = 0; i < 16; ++i) Tn[i] = Tk[i] + dx[i % 6];
-  } /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
-  for (int i = 0; i < 16; ++i) gn->Tk[i] = Tn[i];
-  gn->iteration = iteration + 1;
-  gn->last_error = err;
-  if (result == 0) {
-    gn->converged = 1;
-    gn->done = 1;
-  } else {
-    uint32_t k = gn->k + 1;
-    gn->k = k;
-    uint32_t nh = gn->n_hist;
-    if (history != nullptr && blockIdx.y == 0 && nh < history_cap)
-      for (int i = 0; i < 16; ++i) history[16 * (size_t)nh + i] = Tn[i];
-    gn->n_hist = nh + 1;
-    if (k >= max_iter) gn->done = 1;
-  }
+  if (writer) gout->pending = 1;
 }
 
 static IcpArgs make_args(suma_ctx* c) {
@@ -464,34 +539,53 @@ static IcpArgs make_args(suma_ctx* c) {
   a.weight_function = c->p.weight_function;
   a.bilinear = c->p.bilinear_sampling;
   a.P = (uint32_t)a.W * (uint32_t)a.H;
-  {
-    const char* e = getenv("SUMA_ICP_ABLATE");
-    a.ablate = e ? atoi(e) : 0;
-  }
   return a;
+}
+
+/* state / partial buffers alternate with the launch parity c->gn_launch */
+static GnState* gn_buf(suma_ctx* c, uint32_t parity) { return c->gn + (size_t)(parity & 1u) * SUMA_MAX_HYP; }
+static long long* part_buf(suma_ctx* c, uint32_t parity) {
+  return (long long*)c->gn_partial + (size_t)(parity & 1u) * SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS;
 }
 
 hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0) {
   double* hist = with_history ? c->gn_history : nullptr;
+  c->gn_launch = 0;
   if (n_hyp == 1) {
     PoseD T0;
     for (int i = 0; i < 16; ++i) T0.m[i] = h_T0s[i];
-    k_gn_init1<<<1, 64, 0, c->stream>>>(c->gn, T0, hist, iteration0);
+    k_gn_init1<<<1, 64, 0, c->stream>>>(gn_buf(c, 0), T0, hist, iteration0);
   } else {
     hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) return e;
-    k_gn_init<<<n_hyp, 64, 0, c->stream>>>(c->gn, c->gn_T0s, hist, iteration0);
+    k_gn_init<<<n_hyp, 64, 0, c->stream>>>(gn_buf(c, 0), c->gn_T0s, hist, iteration0);
   }
   return hipGetLastError();
 }
 
+/* one launch of the chain; pixel = 0 is the closing consume-only launch (one block per hypothesis) */
 hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
-                                int eval_only, int with_history) {
-  IcpArgs a = make_args(c);
-  ProfScope ps(c, eval_only ? "k6_icp_eval" : "k6_icp_step", 96.0 * a.P * n_hyp);
-  dim3 grid(c->icp_blocks, n_hyp);
-  k_icp_step<<<grid, ICP_THREADS, 0, c->stream>>>(a, c->gn, (long long*)c->gn_partial, max_iter, epsilon, delta,
-                                                   eval_only, with_history ? c->gn_history : nullptr,
-                                                   c->gn_history_cap);
+                                int eval_only, int with_history, int pixel) {
+  IterArgs g;
+  g.a = make_args(c);
+  g.gin = gn_buf(c, c->gn_launch);
+  g.gout = gn_buf(c, c->gn_launch + 1);
+  g.pin = part_buf(c, c->gn_launch);
+  g.pout = part_buf(c, c->gn_launch + 1);
+  g.nblocks = c->icp_blocks;
+  g.max_iter = max_iter;
+  g.epsilon = epsilon;
+  g.delta_thr = delta;
+  g.eval_only = eval_only;
+  g.pixel = pixel;
+  g.history = with_history ? c->gn_history : nullptr;
+  g.history_cap = c->gn_history_cap;
+  c->gn_launch += 1;
+  ProfScope ps(c, pixel ? (eval_only ? "k6_icp_eval" : "k6_icp_step") : "k6_icp_finish", pixel ? 96.0 * g.a.P * n_hyp : 0.0);
+  dim3 grid(pixel ? c->icp_blocks : 1, n_hyp);
+  k_icp_iter<<<grid, ICP_THREADS, 0, c->stream>>>(g);
   return hipGetLastError();
 }
+
+/* where the result of the last launch lives */
+const GnState* gn_result(suma_ctx* c) { return gn_buf(c, c->gn_launch); }

@@ -274,9 +274,10 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     memset(c->h_ds, 0, sizeof(DevState));
     /* ICP */
     c->icp_blocks = 256;
-    CK(hipMalloc((void**)&c->gn, SUMA_MAX_HYP * sizeof(GnState)));
-    CK(hipMemsetAsync(c->gn, 0, SUMA_MAX_HYP * sizeof(GnState), c->stream));
-    CK(hipMalloc((void**)&c->gn_partial, (size_t)SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS * sizeof(int64_t)));
+    CK(hipMalloc((void**)&c->gn, 2 * SUMA_MAX_HYP * sizeof(GnState)));
+    CK(hipMemsetAsync(c->gn, 0, 2 * SUMA_MAX_HYP * sizeof(GnState), c->stream));
+    CK(hipMalloc((void**)&c->gn_partial, (size_t)2 * SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS * sizeof(int64_t)));
+    c->gn_launch = 0;
     c->gn_history_cap = 1025;
     CK(hipMalloc((void**)&c->gn_history, (size_t)c->gn_history_cap * 16 * sizeof(double)));
     CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
@@ -478,8 +479,9 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
   if (!c || !pose) return SUMA_ERR_INVALID;
   if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
   CK(launch_gn_init(c, pose, 1, 0, iteration));
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0));
-  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   const GnState& g = c->h_gn[0];
   if (JtJ) memcpy(JtJ, g.JtJ, sizeof(g.JtJ));
@@ -495,9 +497,11 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
   uint32_t max_iter = c->p.max_iterations;
   uint32_t launches = max_iter > 0 ? max_iter : 1000; /* reference: 0 = until convergence (LieGaussNewton.cpp:27) */
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
-  for (uint32_t i = 0; i < launches; ++i)
+  /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
+   * closing launch only consumes */
+  for (uint32_t i = 0; i <= launches; ++i)
     CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
-                            (double)c->p.delta, 0, with_history));
+                            (double)c->p.delta, 0, with_history, i < launches ? 1 : 0));
   return SUMA_OK;
 }
 
@@ -508,7 +512,7 @@ extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[
   const int with_history = (history != nullptr && history_cap > 0) ? 1 : 0;
   int r = enqueue_minimize(c, T0, 1, with_history);
   if (r) return r;
-  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   const GnState& g = c->h_gn[0];
   memcpy(T_out, g.Tk, sizeof(g.Tk));
@@ -529,7 +533,7 @@ extern "C" int suma_icp_minimize_batch(suma_ctx* c, const double* T0s, uint32_t 
   if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
   int r = enqueue_minimize(c, T0s, n_hyp, 0);
   if (r) return r;
-  CK(hipMemcpyAsync(c->h_gn, c->gn, (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   for (uint32_t h = 0; h < n_hyp; ++h) {
     memcpy(T_out + 16 * (size_t)h, c->h_gn[h].Tk, 16 * sizeof(double));
@@ -917,7 +921,7 @@ static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_fram
   int r = enqueue_minimize(c, T0, 1, 0);
   c->p = saved;
   if (r) return r;
-  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   c->known_surfels = c->h_ds->n_surfels;
@@ -958,8 +962,9 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;
   CK(launch_gn_init(c, I, 1, 0, 0));
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0)); /* :411-413, statistics only */
-  CK(hipMemcpyAsync(c->h_gn, c->gn, sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1)); /* :411-413, statistics only */
+  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
 
   float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
   float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));

@@ -52,7 +52,7 @@ struct GnState {
   uint32_t k;         /* LieGaussNewton::k_ */
   uint32_t done, converged;
   uint32_t valid, outlier, invalid, n_hist;
-  uint32_t ticket;
+  uint32_t pending; /* a pixel phase has left partial sums that the next launch must consume */
   uint32_t pad[3];
   int64_t acc[SUMA_ACC_WORDS];
   double JtJ[36];
@@ -95,8 +95,9 @@ struct suma_ctx {
 
   /* ICP */
   const suma_frame *icp_current, *icp_model;
-  GnState* gn;        /* SUMA_MAX_HYP states */
-  int64_t* gn_partial; /* SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
+  GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
+  int64_t* gn_partial; /* 2 x SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
+  uint32_t gn_launch;  /* launches since the last gn_init */
   double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
   double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
   uint32_t gn_history_cap;
@@ -195,7 +196,8 @@ hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_la
 /* k_icp.hip */
 hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0);
 hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
-                                int eval_only, int with_history);
+                                int eval_only, int with_history, int pixel);
+const GnState* gn_result(suma_ctx* c);
 /* k_render.hip */
 hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
                              suma_frame* out);
