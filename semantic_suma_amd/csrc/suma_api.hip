@@ -809,6 +809,8 @@ extern "C" int suma_map_counts(suma_ctx* c, uint32_t* n_updated, uint32_t* n_new
 /* ---------------------------------------------------------------------------------------------
  * SurfelMapping::processScan
  * ------------------------------------------------------------------------------------------- */
+static void resolve_stats(suma_pipeline* s, bool need_sync);
+
 static void eye_d(double* T) {
   for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
 }
@@ -853,6 +855,12 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
       return r;
     }
   }
+  if (hipHostMalloc((void**)&s->h_stats, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
+    g_create_error = "hipHostMalloc failed";
+    suma_pipeline_destroy(s);
+    return SUMA_ERR_HIP;
+  }
+  s->stats_pending = false;
   eye_d(s->current_pose);
   eye_d(s->last_pose);
   eye_d(s->pose_old);
@@ -870,6 +878,7 @@ extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
   suma_frame_destroy(s->current_frame);
   suma_frame_destroy(s->current_model);
   suma_frame_destroy(s->last_model);
+  if (s->h_stats) hipHostFree(s->h_stats);
   suma_ctx_destroy(s->c);
   delete s;
 }
@@ -886,6 +895,7 @@ extern "C" int suma_pipeline_last_increment(const suma_pipeline* s, double inc[1
 }
 extern "C" int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st) {
   if (!s || !st) return SUMA_ERR_INVALID;
+  resolve_stats(const_cast<suma_pipeline*>(s), true);
   *st = s->stats;
   return SUMA_OK;
 }
@@ -893,6 +903,18 @@ extern "C" uint32_t suma_pipeline_timestamp(const suma_pipeline* s) { return s ?
 extern "C" suma_frame* suma_pipeline_frame(suma_pipeline* s, int which) {
   if (!s) return nullptr;
   return which == 0 ? s->current_frame : (which == 1 ? s->last_model : s->current_model);
+}
+
+/* the stream has been synchronised (or will be here): turn the pending statistics copy into s->stats */
+static void resolve_stats(suma_pipeline* s, bool need_sync) {
+  if (!s->stats_pending) return;
+  if (need_sync) hipStreamSynchronize(s->c->stream);
+  suma_icp_stats st;
+  fill_stats(*s->h_stats, &st);
+  st.iterations = s->stats_mst.iterations;
+  st.converged = s->stats_mst.converged;
+  s->stats = st;
+  s->stats_pending = false;
 }
 
 /* SurfelMapping::getConfidenceThreshold, SurfelMapping.cpp:333-340 (time_init = 10) */
@@ -924,6 +946,7 @@ static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_fram
   CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
+  resolve_stats(s, false); /* everything enqueued before this point has completed */
   c->known_surfels = c->h_ds->n_surfels;
   memcpy(T, c->h_gn[0].Tk, 16 * sizeof(double));
   fill_stats(c->h_gn[0], st);
@@ -964,18 +987,15 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   CK(launch_gn_init(c, I, 1, 0, 0));
   CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1)); /* :411-413, statistics only */
   CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
-  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  resolve_stats(s, true); /* (no-op unless the previous scan's statistics were never looked at) */
+  CK(hipMemcpyAsync(s->h_stats, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  s->stats_mst = mst;
+  s->stats_pending = true;
 
   float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
   float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));
   float r_err = (float)acos((double)fmaxf(fminf(angle, 1.0f), -1.0f));
   const bool fallback = (s->timestamp > 1 && (t_err > 0.4f || r_err > 0.1f) && c->p.fallback_mode); /* :438-449 */
-  CK(hipStreamSynchronize(c->stream));
-  suma_icp_stats st;
-  fill_stats(c->h_gn[0], &st);
-  st.iterations = mst.iterations;
-  st.converged = mst.converged;
-  s->stats = st;
   if (fallback) {
     s->track_loss += 1;
     suma_params saved = c->p;

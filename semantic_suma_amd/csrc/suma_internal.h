@@ -166,6 +166,11 @@ struct suma_pipeline {
   float log_unstable;
   suma_icp_stats stats;
   uint32_t track_loss;
+  /* the statistics pass of updatePose (SurfelMapping.cpp:411-423) is read back lazily: its copy is
+   * enqueued, and resolved at the next synchronisation point instead of stalling the scan */
+  GnState* h_stats; /* pinned */
+  bool stats_pending;
+  suma_icp_stats stats_mst;
 };
 
 #define HIP_TRY(ctx, expr)                                                                       \
