@@ -226,6 +226,11 @@ struct IterArgs {
   int pixel;     /* 0: consume-only launch (grid.x = 1) */
   double* history;
   uint32_t history_cap;
+  /* first launch of a chain: LieGaussNewton::initialize (LieGaussNewton.cpp:36-51) is folded in --
+   * the start state comes from the kernel arguments instead of gin */
+  int init;
+  uint32_t iteration0;
+  PoseD T0;
 };
 
 /* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
@@ -245,12 +250,12 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
   __shared__ double s_pose[16];
   __shared__ uint32_t s_flag[4]; /* done, iteration */
 
-  /* wave-uniform state (scalar loads) */
-  const uint32_t done_in = gin->done, pending = gin->pending;
-  uint32_t iteration = gin->iteration;
+  /* wave-uniform state (scalar loads), or the start state of a fresh chain */
+  const uint32_t done_in = g.init ? 0u : gin->done, pending = g.init ? 0u : gin->pending;
+  uint32_t iteration = g.init ? g.iteration0 : gin->iteration;
   double Tk[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) Tk[i] = gin->Tk[i];
+  for (int i = 0; i < 16; ++i) Tk[i] = g.init ? g.T0.m[i] : gin->Tk[i];
 
   /* data-frame loads of this lane's first pixel do not depend on the pose: issue them now so that
    * their latency overlaps the prologue */
@@ -284,15 +289,17 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
       s_tot[grp][word] = s;
     }
     __syncthreads();
+    if (threadIdx.x < SUMA_ACC_WORDS) { /* 32 lanes fold the 16 groups; lane 0 then reads 32 words */
+      long long s = 0;
+#pragma unroll
+      for (int q = 0; q < ICP_THREADS / 32; ++q) s += s_tot[q][threadIdx.x];
+      s_wave[0][threadIdx.x] = s;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
       long long tot_acc[SUMA_ACC_WORDS];
 #pragma unroll
-      for (int w = 0; w < SUMA_ACC_WORDS; ++w) {
-        long long s = 0;
-#pragma unroll
-        for (int q = 0; q < ICP_THREADS / 32; ++q) s += s_tot[q][w];
-        tot_acc[w] = s;
-      }
+      for (int w = 0; w < SUMA_ACC_WORDS; ++w) tot_acc[w] = s_wave[0][w];
       const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
 #pragma unroll
       for (int w = 0; w < 27; ++w) tot_acc[w] -= n_inlier * MAGIC_BITS;
@@ -380,6 +387,18 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
     for (int i = 0; i < 16; ++i) Tk[i] = s_pose[i];
     done = s_flag[0];
     iteration = s_flag[1];
+  } else if (writer && g.init) {
+    for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
+    if (g.history != nullptr && blockIdx.y == 0)
+      for (int i = 0; i < 16; ++i) g.history[i] = Tk[i];
+    gout->last_error = (double)3.402823466e+38f; /* LieGaussNewton.cpp:48 */
+    gout->F = gout->F_inlier = 0.0;
+    gout->iteration = iteration; /* Frame2Model::setData / initialize resets it, Frame2Model.cpp:122 */
+    gout->k = 0;
+    gout->n_hist = 1;
+    gout->converged = 0;
+    gout->done = 0;
+    gout->valid = gout->outlier = gout->invalid = 0;
   } else if (writer) {
     /* nothing to consume: carry the state over to the other buffer */
     for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
@@ -551,10 +570,12 @@ static long long* part_buf(suma_ctx* c, uint32_t parity) {
 hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0) {
   double* hist = with_history ? c->gn_history : nullptr;
   c->gn_launch = 0;
+  c->gn_init_pending = 0;
   if (n_hyp == 1) {
-    PoseD T0;
-    for (int i = 0; i < 16; ++i) T0.m[i] = h_T0s[i];
-    k_gn_init1<<<1, 64, 0, c->stream>>>(gn_buf(c, 0), T0, hist, iteration0);
+    /* single chain: no launch here, the first k_icp_iter takes the start state by value */
+    for (int i = 0; i < 16; ++i) c->gn_T0_host[i] = h_T0s[i];
+    c->gn_iteration0 = iteration0;
+    c->gn_init_pending = 1;
   } else {
     hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream);
     if (e != hipSuccess) return e;
@@ -580,6 +601,10 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.pixel = pixel;
   g.history = with_history ? c->gn_history : nullptr;
   g.history_cap = c->gn_history_cap;
+  g.init = c->gn_init_pending;
+  g.iteration0 = c->gn_iteration0;
+  for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];
+  c->gn_init_pending = 0;
   c->gn_launch += 1;
   ProfScope ps(c, pixel ? (eval_only ? "k6_icp_eval" : "k6_icp_step") : "k6_icp_finish", pixel ? 96.0 * g.a.P * n_hyp : 0.0);
   dim3 grid(pixel ? c->icp_blocks : 1, n_hyp);

@@ -275,7 +275,11 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
   /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
   const bool in_tex = (imx >= 0.0f && imx < a.q.width && imy >= 0.0f && imy < a.q.height);
   const int32_t tx = in_tex ? (int32_t)sdm_floor(imx) : -1, ty = in_tex ? (int32_t)sdm_floor(imy) : -1;
+  /* all five gathers of this measurement pixel are issued together (semantic, radius and the K7
+   * winner are only needed on some paths, but fetching them now removes two dependent round trips) */
   const float4 dv = texel(a.V, W, H, tx, ty), dn = texel(a.N, W, H, tx, ty);
+  const float4 ds = texel(a.Sem, W, H, tx, ty), rc = texel(a.radius_conf, W, H, tx, ty);
+  const unsigned long long k7key = a.zbuf[(size_t)max(ty, 0) * W + (size_t)max(tx, 0)];
   const bool valid = (dv.w > 0.5f) && (dn.w > 0.5f);
   /* quirk B-6: all(lessThan(img, dim)) && !all(lessThan(img, 0)) */
   const bool inside =
@@ -286,7 +290,6 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
   bool mark = false;
 
   if (valid && inside && visible) {
-    const float4 ds = texel(a.Sem, W, H, tx, ty);
     const float data_label = ds.x * 255.0f, data_prob = ds.w;
     const float model_label = in.d.x * 255.0f, model_prob = in.d.w;
     if (sdm_round(data_label) != sdm_round(model_label)) {
@@ -298,7 +301,6 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
     const v3 view_dir = divs3(neg3(v), len3(v));
     const float distance = sdm_abs(dot3(old_normal, sub3(v_global, old_position)));
     const float angle = len3(cross3(n_global, old_normal));
-    const float4 rc = texel(a.radius_conf, W, H, tx, ty);
     const float new_radius = rc.x, new_confidence = rc.y;
 
     if ((distance < a.map_max_distance) && (angle < a.update_angle_thresh)) {
@@ -355,8 +357,7 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
       }
     } else {
       /* K7 winner of this measurement pixel */
-      unsigned long long key = a.zbuf[(size_t)ty * W + tx];
-      int32_t idx = (key == SUMA_EMPTY_KEY) ? -1 : (int32_t)(uint32_t)(key & 0xffffffffull);
+      int32_t idx = (k7key == SUMA_EMPTY_KEY) ? -1 : (int32_t)(uint32_t)(k7key & 0xffffffffull);
       if (idx == (int32_t)i) {
         update_confidence = sdm_log(a.p_unstable / (1.0f - a.p_unstable));
         o.c.y = pack_rgb(0.0f, 1.0f, 1.0f);

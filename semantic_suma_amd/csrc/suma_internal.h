@@ -98,6 +98,9 @@ struct suma_ctx {
   GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
   int64_t* gn_partial; /* 2 x SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
   uint32_t gn_launch;  /* launches since the last gn_init */
+  int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
+  uint32_t gn_iteration0;
+  double gn_T0_host[16];
   double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
   double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
   uint32_t gn_history_cap;
