@@ -120,20 +120,44 @@ __device__ __forceinline__ void finalise_tickets(DevState* ds, unsigned long lon
   if (threadIdx.x == 0) ds->ticket = 0;
 }
 
+/* inverse of a rigid transform evaluated in double from the fp32 matrix, rounded once:
+ * R^T, -R^T t (the reference uses a general inverse, update_surfels.vert:197; equal to fp32
+ * rounding on rigid poses) */
+__device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
+  double R[9], t[3];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
+  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
+  for (int c = 0; c < 3; ++c)
+    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
+  for (int r = 0; r < 3; ++r) {
+    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
+    out[12 + r] = (float)(-s);
+  }
+  out[3] = out[7] = out[11] = 0.0f;
+  out[15] = 1.0f;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * K8 + clear of the integration mask
  * ------------------------------------------------------------------------------------------- */
 __global__ void __launch_bounds__(256)
     k8_radius(const float4* __restrict__ V, const float4* __restrict__ N, float4* __restrict__ radius_conf,
               uint8_t* __restrict__ integrated, uint32_t P, float pixel_size, float angle_thresh, float min_radius,
-              float max_radius, DevState* ds) {
+              float max_radius, DevState* ds, float* poses, float* poses_inv, uint32_t pose_idx, m4 pose) {
   uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= P) return;
-  if (pix == 0) { /* per-update counters */
+  if (pix == 0) { /* per-update counters + SurfelMap.cpp:494-495: poses_[timestamp_] = pose */
     ds->n_updated = 0;
     ds->n_data = 0;
     ds->n_kept_updated = 0;
     ds->n_kept_data = 0;
+    float inv[16];
+    rigid_inverse_dev(pose.m, inv);
+    for (int i = 0; i < 16; ++i) {
+      poses[16 * (size_t)pose_idx + i] = pose.m[i];
+      poses_inv[16 * (size_t)pose_idx + i] = inv[i];
+    }
   }
   float4 v = V[pix], n = N[pix];
   v3 vv = xyz(v), nn = xyz(n);
@@ -593,7 +617,8 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   {
     ProfScope ps(c, "k8_radius", 48.0 * P);
     k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, c->radius_conf, c->integrated, P, c->mc.pixel_size,
-                                                c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds);
+                                                c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds, c->poses,
+                                                c->poses_inv, c->timestamp, a.pose);
   }
   if (!k7_done) { /* otherwise the splat was fused into the post-ICP render pass (same pose, same map) */
     ProfScope ps(c, "k7_indexmap", 64.0 * S + 8.0 * P);
@@ -619,24 +644,6 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
 /* ---------------------------------------------------------------------------------------------
  * pose table (SurfelMap.cpp:494-495, 485-490): poses and their rigid inverses
  * ------------------------------------------------------------------------------------------- */
-/* inverse of a rigid transform evaluated in double from the fp32 matrix, rounded once:
- * R^T, -R^T t (the reference uses a general inverse, update_surfels.vert:197; equal to fp32
- * rounding on rigid poses) */
-__device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
-  double R[9], t[3];
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
-  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
-  for (int r = 0; r < 3; ++r) {
-    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
-    out[12 + r] = (float)(-s);
-  }
-  out[3] = out[7] = out[11] = 0.0f;
-  out[15] = 1.0f;
-}
-
 __global__ void k_set_pose1(float* poses, float* poses_inv, uint32_t idx, m4 pose) {
   if (threadIdx.x != 0) return;
   float inv[16];

@@ -630,7 +630,7 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
     return fail(c, SUMA_ERR_INVALID, "suma_map_update: frame size differs from data_width x data_height");
   if (c->timestamp >= c->p.max_poses)
     return fail(c, SUMA_ERR_CAPACITY, "pose table full (max_poses; reference: maxPoses_ = 10000, SurfelMap.h:205)");
-  CK(launch_set_pose(c, c->timestamp, pose)); /* SurfelMap.cpp:494-495 */
+  /* SurfelMap.cpp:494-495 (poses_[timestamp_] = pose) is done by the first kernel of the update */
   float inv_pose[16];
   rigid_inverse_f(pose, inv_pose);
   /* K11 area, SurfelMap.cpp:667-677 */
