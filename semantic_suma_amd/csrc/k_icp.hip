@@ -69,7 +69,9 @@ __device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map,
 /* raw magic-number bits of round(term * 2^28); MAGIC_BITS is subtracted once per term after the
  * reduction (count * MAGIC_BITS, modulo 2^64) */
 __device__ __forceinline__ long long fix_bits(float term) {
-  double d = (double)term * SUMA_ACC_SCALE + MAGIC_D;
+  /* one v_fma_f64: the product with 2^28 is exact, so fusing changes nothing numerically (this
+   * file is otherwise compiled with -ffp-contract=off, which would split it into ldexp + add) */
+  double d = __builtin_fma((double)term, SUMA_ACC_SCALE, MAGIC_D);
   return __double_as_longlong(d);
 }
 
@@ -93,10 +95,30 @@ __device__ __forceinline__ void reduce_stage(long long (&a)[SUMA_ACC_WORDS], int
     a[i] = keep + shfl_xor_ll(send, MASK);
   }
 }
+/* Stages 32 and 16 of the butterfly with gfx950's lane-swap instructions: v_permlane32_swap
+ * exchanges the upper half of one register with the lower half of another (v_permlane16_swap: odd
+ * rows with even rows), which is exactly "lower lanes keep word i and receive the partner's word
+ * i, upper lanes keep word i+H and receive the partner's word i+H" -- the stage becomes
+ * swap(lo), swap(hi), 64-bit add: no LDS crossbar, no selects. */
+template <int H, bool SWAP32>
+__device__ __forceinline__ void reduce_stage_swap(long long (&a)[SUMA_ACC_WORDS]) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    unsigned int x_lo = (unsigned int)a[i], x_hi = (unsigned int)(a[i] >> 32);
+    unsigned int y_lo = (unsigned int)a[i + H], y_hi = (unsigned int)(a[i + H] >> 32);
+    auto lo = SWAP32 ? __builtin_amdgcn_permlane32_swap(x_lo, y_lo, false, false)
+                     : __builtin_amdgcn_permlane16_swap(x_lo, y_lo, false, false);
+    auto hi = SWAP32 ? __builtin_amdgcn_permlane32_swap(x_hi, y_hi, false, false)
+                     : __builtin_amdgcn_permlane16_swap(x_hi, y_hi, false, false);
+    long long p = (long long)(((unsigned long long)hi[0] << 32) | lo[0]);
+    long long q = (long long)(((unsigned long long)hi[1] << 32) | lo[1]);
+    a[i] = p + q;
+  }
+}
 __device__ __forceinline__ long long wave_reduce32(long long (&a)[SUMA_ACC_WORDS], int lane) {
   /* explicit stages: every index is a compile-time constant, the words stay in VGPRs */
-  reduce_stage<16, 32>(a, lane);
-  reduce_stage<8, 16>(a, lane);
+  reduce_stage_swap<16, true>(a);
+  reduce_stage_swap<8, false>(a);
   reduce_stage<4, 8>(a, lane);
   reduce_stage<2, 4>(a, lane);
   reduce_stage<1, 2>(a, lane);
