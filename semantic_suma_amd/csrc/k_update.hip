@@ -474,6 +474,8 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
   __shared__ uint32_t s_tile;
   __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES];
   __shared__ uint32_t s_prefix;
+  __shared__ uint8_t s_flag[SUMA_TILE];
+  __shared__ uint32_t s_rank[SUMA_TILE];
   const int32_t W = a.q.W, H = a.q.H;
   const uint32_t P = (uint32_t)W * (uint32_t)H;
   const uint32_t ntiles = (P + SUMA_TILE - 1) / SUMA_TILE;
@@ -487,7 +489,21 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     __syncthreads();
     const uint32_t tile = s_tile;
     if (tile >= ntiles) break;
-    const uint32_t t = tile * SUMA_TILE + threadIdx.x; /* x-major item index */
+    /* A tile is SUMA_TILE consecutive items of the x-major emission order, i.e. (when H divides
+     * SUMA_TILE) a patch of SUMA_TILE / H whole image columns.  Lanes walk the patch ROW-major so
+     * that the map reads are 16-texel segments instead of one texel per 32 KiB row stride; the
+     * x-major rank every lane needs for the stable compaction is obtained by exchanging the flags
+     * through LDS. */
+    const bool patch = (SUMA_TILE % (uint32_t)H) == 0;
+    const uint32_t cols = patch ? SUMA_TILE / (uint32_t)H : 1u;
+    uint32_t q; /* x-major index of this lane's pixel inside the tile */
+    if (patch) {
+      const uint32_t yy = threadIdx.x / cols, xx = threadIdx.x - yy * cols;
+      q = xx * (uint32_t)H + yy;
+    } else {
+      q = threadIdx.x;
+    }
+    const uint32_t t = tile * SUMA_TILE + q; /* x-major item index */
     bool gen = false, emit = false;
     Surfel4 s;
     if (t < P) {
@@ -520,7 +536,11 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
       const unsigned long long gb = __ballot(gen);
       if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(gb);
     }
-    BlockRank br = block_rank(emit, s_wave_a);
+    /* rank in x-major order: flags -> LDS[q], ranked by the lane whose id is the x-major index */
+    s_flag[q] = emit ? 1 : 0;
+    __syncthreads();
+    BlockRank br = block_rank(s_flag[threadIdx.x] != 0, s_wave_a);
+    s_rank[threadIdx.x] = br.rank;
     if (threadIdx.x == 0)
       for (int w = 0; w < (int)TILE_WAVES; ++w) new_count += s_wave_b[w];
     if (threadIdx.x < 64) {
@@ -529,7 +549,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     }
     __syncthreads();
     if (emit) {
-      uint64_t dst = (uint64_t)base + s_prefix + br.rank;
+      uint64_t dst = (uint64_t)base + s_prefix + s_rank[q];
       if (dst < a.max_surfels) store_surfel(a.out, (uint32_t)dst, s);
     }
     if (tile == ntiles - 1 && threadIdx.x == 0) {
