@@ -142,7 +142,9 @@ int suma_device_free(suma_ctx* ctx, void* d_ptr);
 int suma_device_upload(suma_ctx* ctx, void* d_dst, const void* host_src, uint64_t bytes);
 
 /* ---- per-kernel timing (rv::Stopwatch / SurfelMapping::Stats, SurfelMapping.cpp:183-207):
- *      when enabled every kernel launch is bracketed by HIP events on the ctx stream.
+ *      on = 1: every kernel group is bracketed by HIP events on the ctx stream; on = 2: only the
+ *      Gauss-Newton chain (the kernel with the largest share of GPU time), which costs two event
+ *      records per scan and leaves the throughput undisturbed; on = 0: off.
  *      suma_profile_get fills up to cap entries, returns the number of distinct kernels. */
 typedef struct suma_kernel_time {
   char name[48];

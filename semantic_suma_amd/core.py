@@ -170,8 +170,9 @@ class Context:
         self.check(self.L.suma_device_free(self.h, C.c_void_p(p)), "suma_device_free")
 
     # profiling
-    def profile(self, on: bool):
-        self.check(self.L.suma_profile_enable(self.h, 1 if on else 0))
+    def profile(self, on):
+        """0 / False: off, 1 / True: every kernel group, 2: only the Gauss-Newton chain (two events per scan)"""
+        self.check(self.L.suma_profile_enable(self.h, int(on)))
 
     def profile_reset(self):
         self.check(self.L.suma_profile_reset(self.h))

@@ -261,7 +261,8 @@ struct IterArgs {
  *             (LieGaussNewton::step, LieGaussNewton.cpp:53-79).  Done by every block on its own
  *             copy (identical inputs, identical code => identical results); block 0 records it.
  *   body:     unless finished, the K6 pixel phase at the current pose -> one partial per block. */
-__global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
+template <bool PIXEL>
+__device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   const IcpArgs& a = g.a;
   const GnState* __restrict__ gin = g.gin + blockIdx.y;
   GnState* __restrict__ gout = g.gout + blockIdx.y;
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
   /* data-frame loads of this lane's first pixel do not depend on the pose: issue them now so that
    * their latency overlaps the prologue */
   const uint32_t pix0 = blockIdx.x * ICP_THREADS + threadIdx.x;
-  const bool want_px = g.pixel && !(done_in && !pending);
+  const bool want_px = PIXEL && !(done_in && !pending);
   float4 vd4 = f4(0, 0, 0, 0), nd4 = vd4, sd4 = vd4;
   if (want_px && pix0 < a.P) {
     vd4 = a.Vd[pix0];
@@ -439,7 +440,7 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
       for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = gin->acc[w];
   }
 
-  if (!g.pixel || (done && !g.eval_only) || (g.eval_only && pending)) {
+  if (!PIXEL || (done && !g.eval_only) || (g.eval_only && pending)) {
     if (writer) gout->pending = 0;
     return;
   }
@@ -558,6 +559,10 @@ __global__ void __launch_bounds__(ICP_THREADS) k_icp_iter(IterArgs g) {
   if (writer) gout->pending = 1;
 }
 
+/* two entry points so that profiles tell the pixel launches from the closing consume-only launch */
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_step(IterArgs g) { icp_iter_body<true>(g); }
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_finish(IterArgs g) { icp_iter_body<false>(g); }
+
 static IcpArgs make_args(suma_ctx* c) {
   IcpArgs a;
   const suma_frame *cur = c->icp_current, *mod = c->icp_model;
@@ -628,9 +633,11 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];
   c->gn_init_pending = 0;
   c->gn_launch += 1;
-  ProfScope ps(c, pixel ? (eval_only ? "k6_icp_eval" : "k6_icp_step") : "k6_icp_finish", pixel ? 96.0 * g.a.P * n_hyp : 0.0);
   dim3 grid(pixel ? c->icp_blocks : 1, n_hyp);
-  k_icp_iter<<<grid, ICP_THREADS, 0, c->stream>>>(g);
+  if (pixel)
+    k_icp_step<<<grid, ICP_THREADS, 0, c->stream>>>(g);
+  else
+    k_icp_finish<<<grid, ICP_THREADS, 0, c->stream>>>(g);
   return hipGetLastError();
 }
 

@@ -85,7 +85,7 @@ static int fail(suma_ctx* c, int code, const char* msg) {
 /* ---------------------------------------------------------------------------------------------
  * profiling
  * ------------------------------------------------------------------------------------------- */
-int prof_begin(suma_ctx* c, const char* name, double bytes) {
+int prof_begin(suma_ctx* c, const char* name, double bytes, uint32_t launches) {
   int id = -1;
   for (size_t i = 0; i < c->prof_names.size(); ++i)
     if (c->prof_names[i] == name) id = (int)i;
@@ -99,6 +99,7 @@ int prof_begin(suma_ctx* c, const char* name, double bytes) {
   ProfEvent ev;
   ev.id = id;
   ev.bytes = bytes;
+  ev.launches = launches;
   for (hipEvent_t* e : {&ev.a, &ev.b}) { /* events are pooled: creation is not on the per-launch path */
     if (!c->prof_pool.empty()) {
       *e = c->prof_pool.back();
@@ -121,7 +122,7 @@ static void prof_collect(suma_ctx* c) {
     if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
       c->prof_ms[ev.id] += ms;
       c->prof_bytes[ev.id] += ev.bytes;
-      c->prof_launches[ev.id] += 1;
+      c->prof_launches[ev.id] += ev.launches;
     }
     c->prof_pool.push_back(ev.a);
     c->prof_pool.push_back(ev.b);
@@ -132,7 +133,8 @@ static void prof_collect(suma_ctx* c) {
 extern "C" int suma_profile_enable(suma_ctx* c, int on) {
   if (!c) return SUMA_ERR_INVALID;
   prof_collect(c);
-  c->profiling = on != 0;
+  c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
+  if (c->prof_filter.empty()) c->prof_filter = "k6_icp_step";
   return SUMA_OK;
 }
 extern "C" int suma_profile_reset(suma_ctx* c) {
@@ -233,7 +235,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   }
   c->p = *params;
   c->device = hip_device;
-  c->profiling = false;
+  c->profiling = 0;
   c->epoch = 0;
   c->scan_cap = 0;
   c->scan_points = nullptr;
@@ -479,8 +481,14 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
   if (!c || !pose) return SUMA_ERR_INVALID;
   if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
   CK(launch_gn_init(c, pose, 1, 0, iteration));
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  {
+    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->icp_current->width * c->icp_current->height);
+    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
+  }
+  {
+    ProfScope ps(c, "k6_icp_finish", 0.0);
+    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  }
   CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   const GnState& g = c->h_gn[0];
@@ -499,9 +507,19 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
-  for (uint32_t i = 0; i <= launches; ++i)
+  const double chain_bytes = 96.0 * (double)c->icp_current->width * c->icp_current->height * n_hyp * launches;
+  {
+    /* one event pair around the whole chain of identical pixel launches: per-launch time = chain / N */
+    ProfScope ps(c, "k6_icp_step", chain_bytes, launches);
+    for (uint32_t i = 0; i < launches; ++i)
+      CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
+                              (double)c->p.delta, 0, with_history, 1));
+  }
+  {
+    ProfScope ps(c, "k6_icp_finish", 0.0);
     CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
-                            (double)c->p.delta, 0, with_history, i < launches ? 1 : 0));
+                            (double)c->p.delta, 0, with_history, 0));
+  }
   return SUMA_OK;
 }
 
@@ -985,8 +1003,14 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;
   CK(launch_gn_init(c, I, 1, 0, 0));
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1)); /* :411-413, statistics only */
-  CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  {
+    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
+    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1)); /* :411-413, statistics only */
+  }
+  {
+    ProfScope ps(c, "k6_icp_finish", 0.0);
+    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  }
   resolve_stats(s, true); /* (no-op unless the previous scan's statistics were never looked at) */
   CK(hipMemcpyAsync(s->h_stats, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   s->stats_mst = mst;

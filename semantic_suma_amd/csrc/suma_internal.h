@@ -74,6 +74,7 @@ struct ProfEvent {
   hipEvent_t a, b;
   int id;
   double bytes;
+  uint32_t launches; /* kernel launches bracketed by this event pair (a chain of identical launches) */
 };
 
 struct suma_ctx {
@@ -135,7 +136,8 @@ struct suma_ctx {
   std::vector<std::pair<int32_t, int32_t>> extraction;        /* pending tiles, used as a stack */
 
   /* profiling */
-  bool profiling;
+  int profiling; /* 0 off, 1 every kernel group, 2 only the group named prof_filter */
+  std::string prof_filter;
   std::vector<ProfEvent> prof_events;
   std::vector<hipEvent_t> prof_pool;
   std::vector<std::string> prof_names;
@@ -186,12 +188,13 @@ struct suma_pipeline {
   } while (0)
 
 /* profiling scope: brackets the launches of one named kernel with events on the ctx stream */
-int prof_begin(suma_ctx* c, const char* name, double bytes);
+int prof_begin(suma_ctx* c, const char* name, double bytes, uint32_t launches);
 void prof_end(suma_ctx* c, int token);
 struct ProfScope {
   suma_ctx* c;
   int tok;
-  ProfScope(suma_ctx* c_, const char* name, double bytes) : c(c_), tok(c_->profiling ? prof_begin(c_, name, bytes) : -1) {}
+  ProfScope(suma_ctx* c_, const char* name, double bytes, uint32_t launches = 1)
+      : c(c_), tok((c_->profiling == 1 || (c_->profiling == 2 && c_->prof_filter == name)) ? prof_begin(c_, name, bytes, launches) : -1) {}
   ~ProfScope() {
     if (tok >= 0) prof_end(c, tok);
   }
