@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--cpu-scans", type=int, default=20, help="scans of the CPU-oracle baseline sample (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed per-kernel HIP-event pass")
     ap.add_argument("--profile-scans", type=int, default=20, help="scans of the untimed per-kernel pass")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--kernels-json", default=os.path.join(ROOT, "gpurun_out", "bench_kernels.json"))
     args = ap.parse_args()
 
@@ -69,10 +70,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # one process per GPU; SUMA_BENCH_FORCE_DEVICE is a debugging aid (several ranks on one GPU with gloo)
+    local_rank = int(os.environ.get("SUMA_BENCH_FORCE_DEVICE", local_rank))
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
 
     from semantic_suma_amd import core, synth
     from semantic_suma_amd.distributed import gather_poses
@@ -111,11 +119,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(Wu, Wu + K):
         pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
-    poses = gather_poses(pipe.getCurrentPose(), device=torch.device("cuda", local_rank)) if world > 1 else None
+    poses = gather_poses(pipe.getCurrentPose(), device=coll_dev) if world > 1 else None
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         assert poses.shape[0] == world
