@@ -336,3 +336,31 @@ def test_error_paths(hip):
     p_bad = params_with_size(1024)
     with pytest.raises(hip.SumaError):
         ctx.set_params(p_bad)  # geometry is fixed at creation
+
+
+def test_highres_128x4096_pipeline(hip, oracle_lib):
+    """BASELINE config 5 geometry (128 beams x 4096 columns): two scans end to end, bit for bit.
+    Exercises > 1 pixel per lane in K6, 512 compaction tiles in K10 and H = 128 patches."""
+    p = params_with_size(4096, 128, data_fov_down=-25.0, model_fov_down=-25.0)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for k in range(2):
+        pts, lab, prob, _ = get_scan(k, 4096, True, 128)
+        hp.processScan(pts, lab, prob, fixed_iterations=5)
+        op.process_scan(pts, lab, prob, fixed_iterations=5)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k} pose"
+        assert hp.map.size() == op.ctx.map_size() and hp.map.size() > 100000
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        frames_equal(hp.frame(2), op.frame(2), f"scan {k} model frame")
+    assert hp.lastStats().as_dict() == op.last_stats().as_dict()
+
+
+def test_capacity_overflow_is_reported(hip):
+    """the reference silently truncates when transform feedback overflows (SurfelMap.cpp:726-727);
+    here the map is truncated the same way but the condition is reported"""
+    p = params_with_size(900, max_surfels=5000)
+    hp = hip.SurfelMapping(p)
+    pts, lab, prob, _ = get_scan(0, 900, True)
+    hp.processScan(pts, lab, prob)
+    with pytest.raises(hip.SumaError, match="capacity"):
+        hp.map.size()
