@@ -26,7 +26,8 @@ import numpy as np
 from .types import ACC_WORDS, SURFEL_DTYPE, IcpStats, SumaParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsuma_hip.so")
+# SUMA_HIP_LIB selects another build of the same library (A/B timing of kernel variants in one GPU session)
+LIB_PATH = os.environ.get("SUMA_HIP_LIB") or os.path.join(_HERE, "libsuma_hip.so")
 _LIB = None
 
 
