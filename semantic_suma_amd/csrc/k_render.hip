@@ -86,7 +86,7 @@ __device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t 
  * of depth and disc coordinates, disc + near/far tests, depth-tested write.  Every quantity is a
  * function of the triangle and the pixel only, so the work can be distributed freely over lanes. */
 __device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, int32_t j, int32_t W,
-                                             unsigned long long* __restrict__ zbuf, uint32_t id, int tie, int ablate = 0) {
+                                             unsigned long long* __restrict__ zbuf, uint32_t id, int tie) {
   long long area = edge_fn(A, B, C.X, C.Y);
   if (area == 0) return;
   if (area < 0) {
@@ -107,8 +107,6 @@ __device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, 
   if ((tu * tu + tv * tv) > 1.0f) return; /* render_surfels.frag:22 */
   float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
   if (!(z >= 0.0f && z <= 1.0f)) return; /* near / far clipping */
-  if (ablate == 6) { zbuf[(size_t)j * (size_t)W + (size_t)i] = render_key(depth24(z), id, tie); return; }
-  if (ablate == 7) { unsigned long long k = render_key(depth24(z), id, tie); if (k == 12345) zbuf[0] = k; return; }
   atomicMin(&zbuf[(size_t)j * (size_t)W + (size_t)i], render_key(depth24(z), id, tie));
 }
 
@@ -130,20 +128,46 @@ __device__ __forceinline__ void surfel_to_sensor(const float* __restrict__ poses
   *n = m4_dir(M, nrm);
 }
 
-/* K4.  Phase 1 (lane per surfel): transform, gate, project the four quad corners, clip the
- * bounding box.  Phase 2 (wave cooperative): the pixel tests of all 64 surfels of the wave are
- * laid end to end (prefix sum of the box areas) and handed out 64 at a time, so a lane with a large
- * footprint no longer stalls 63 lanes with empty ones: at 64x2048 the median surfel covers no
- * pixel centre at all, the mean box is 3.6 tests, but the mean per-wave maximum is 14 -- a
- * lane-per-surfel raster loop ran 7x longer than the work it contained. */
+/* K4 in three block-cooperative phases.
+ *  1a (lane per surfel)   transform to the sensor frame, stability / age / back-face / image gating,
+ *                         projection of the centre (and the fused K7 splat).  Survivors -- about
+ *                         40 % of the lanes -- are COMPACTED into an LDS list.
+ *  1b (lane per survivor) tangent frame, projection of the four quad corners, clipped bounding box.
+ *                         Running this on dense lanes instead of under a 40 %-full exec mask removes
+ *                         most of the kernel's ALU time (5 spherical projections per surfel).
+ *  2  (lane per pixel test) the pixel tests of all survivors of the block are laid end to end
+ *                         (prefix sum of the box areas) and handed out 256 at a time: at 64x2048 the
+ *                         median surfel covers no pixel centre, the mean box is 3.6 tests, but the mean
+ *                         per-wave maximum is 14 -- a lane-per-surfel raster loop ran 7x longer than
+ *                         the work it contained. */
 #define RENDER_THREADS 256
+#define RENDER_WAVES (RENDER_THREADS / 64)
+
+/* exclusive rank of `flag` among the block's threads + block total (all threads call) */
+__device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ball = __ballot(flag);
+  if (lane == 0) s_w[wave] = __popcll(ball);
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < RENDER_WAVES; ++w) {
+    uint32_t c = s_w[w];
+    if (w < wave) off += c;
+    tot += c;
+  }
+  *total = tot;
+  return off + __popcll(ball & ((1ull << lane) - 1ull));
+}
+
 __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
-  __shared__ int32_t s_rec[RENDER_THREADS][16]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, - */
+  __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
+  __shared__ int32_t s_rec[RENDER_THREADS][16]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id */
   __shared__ uint32_t s_incl[RENDER_THREADS];
+  __shared__ uint32_t s_w[2][RENDER_WAVES];
   const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
-  const int lane = threadIdx.x & 63;
-  const int wbase = threadIdx.x & ~63;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (uint32_t blk0 = blockIdx.x * RENDER_THREADS; blk0 < S; blk0 += gridDim.x * RENDER_THREADS) {
     const uint32_t i = blk0 + threadIdx.x;
     float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
@@ -157,110 +181,140 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
     const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
-    if (a.k7_enabled && i < S) {
-      /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
-      v3 p, n;
-      surfel_to_sensor(a.poses, a.slot[0].inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
-      float lp = len3(p);
-      if (dot3(n, divs3(neg3(p), lp)) > 0.01f) {
-        v3 pr = project01(a.k7_q, p);
-        float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
-        float zn = 2.0f * pr.z - 1.0f;
-        if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
-          unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
-          atomicMin(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
-        }
-      }
-    }
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       const RenderSlot& slot = a.slot[sl];
       if (!slot.enabled) continue; /* kernel-uniform */
-      /* ---- phase 1 ---- */
-      uint32_t ntests = 0;
-      if (live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr))) {
-        v3 p, n;
+      /* ---- phase 1a ---- */
+      const bool selected = live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr));
+      const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
+      bool cand = false;
+      v3 p = mk3(0, 0, 0), n = p;
+      float ppx = 0.f;
+      if (selected || k7) {
         surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
-        /* cheap rejections first (back-facing / outside the image); same predicate as
-         * render_surfels.geom:83-92, evaluated before the tangent frame is built */
         float lp = len3(p);
-        bool visible = dot3(n, divs3(neg3(p), lp)) > 0.01f;
-        v3 pp = project01(a.q, p);
-        if (visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f) {
-          v3 u = normalize3(mk3(n.y - n.z, -n.x, n.x));
-          v3 v = normalize3(cross3(n, u));
-          v3 ru = scale3(radius, u), rv = scale3(radius, v);
-          v3 corner[4];
-          corner[0] = sub3(sub3(p, ru), rv);
-          corner[1] = sub3(add3(p, ru), rv);
-          corner[2] = add3(sub3(p, ru), rv);
-          corner[3] = add3(add3(p, ru), rv);
-          int32_t X[4], Y[4];
-          float Z[4];
-          bool bad = false;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            v3 pr = project01(a.q, corner[k]);
-            /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
-            if (pp.x - pr.x > 0.5f) pr.x += 1.0f;
-            if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
-            float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
-            if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
-            X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
-            Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
-            Z[k] = pr.z;
-          }
-          if (!bad) {
-            const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
-            const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
-            int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel centres inside the box */
-            int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
-            i0 = max(i0, 0);
-            j0 = max(j0, 0);
-            i1 = min(i1, a.q.W - 1);
-            j1 = min(j1, a.q.H - 1);
-            if (i0 <= i1 && j0 <= j1) {
-              const int32_t w = i1 - i0 + 1;
-              ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
-              int32_t* r = s_rec[threadIdx.x];
-#pragma unroll
-              for (int k = 0; k < 4; ++k) {
-                r[k] = X[k];
-                r[4 + k] = Y[k];
-                r[8 + k] = __float_as_int(Z[k]);
-              }
-              r[12] = i0;
-              r[13] = j0;
-              r[14] = w;
+        if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
+          if (k7) {
+            /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
+            v3 pr = project01(a.k7_q, p);
+            float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
+            float zn = 2.0f * pr.z - 1.0f;
+            if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
+              unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
+              atomicMin(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
             }
+          }
+          if (selected) {
+            v3 pp = project01(a.q, p);
+            cand = (pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f);
+            ppx = pp.x;
           }
         }
       }
-      /* inclusive prefix of the test counts over the wave */
+      uint32_t ncand;
+      const uint32_t crank = render_block_rank(cand, s_w[0], &ncand);
+      if (cand) {
+        float* r = s_cand[crank];
+        r[0] = p.x;
+        r[1] = p.y;
+        r[2] = p.z;
+        r[3] = n.x;
+        r[4] = n.y;
+        r[5] = n.z;
+        r[6] = radius;
+        r[7] = ppx;
+        r[8] = __uint_as_float(i);
+      }
+      __syncthreads();
+      /* ---- phase 1b: dense lanes ---- */
+      uint32_t ntests = 0;
+      if (threadIdx.x < ncand) {
+        const float* r = s_cand[threadIdx.x];
+        const v3 cp = mk3(r[0], r[1], r[2]), cn = mk3(r[3], r[4], r[5]);
+        const float crad = r[6], cppx = r[7];
+        v3 u = normalize3(mk3(cn.y - cn.z, -cn.x, cn.x));
+        v3 v = normalize3(cross3(cn, u));
+        v3 ru = scale3(crad, u), rv = scale3(crad, v);
+        v3 corner[4];
+        corner[0] = sub3(sub3(cp, ru), rv);
+        corner[1] = sub3(add3(cp, ru), rv);
+        corner[2] = add3(sub3(cp, ru), rv);
+        corner[3] = add3(add3(cp, ru), rv);
+        int32_t X[4], Y[4];
+        float Z[4];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v3 pr = project01(a.q, corner[k]);
+          /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
+          if (cppx - pr.x > 0.5f) pr.x += 1.0f;
+          if (pr.x - cppx > 0.5f) pr.x -= 1.0f;
+          float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
+          if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
+          X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
+          Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
+          Z[k] = pr.z;
+        }
+        if (!bad) {
+          const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
+          const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
+          int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel centres inside the box */
+          int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
+          i0 = max(i0, 0);
+          j0 = max(j0, 0);
+          i1 = min(i1, a.q.W - 1);
+          j1 = min(j1, a.q.H - 1);
+          if (i0 <= i1 && j0 <= j1) {
+            const int32_t w = i1 - i0 + 1;
+            ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
+            int32_t* q = s_rec[threadIdx.x];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              q[k] = X[k];
+              q[4 + k] = Y[k];
+              q[8 + k] = __float_as_int(Z[k]);
+            }
+            q[12] = i0;
+            q[13] = j0;
+            q[14] = w;
+            q[15] = __float_as_int(r[8]);
+          }
+        }
+      }
+      /* inclusive prefix of the test counts over the block */
       uint32_t incl = ntests;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) {
         uint32_t o = __shfl_up(incl, d, 64);
         if (lane >= d) incl += o;
       }
-      const uint32_t total = __shfl(incl, 63, 64);
-      s_incl[threadIdx.x] = incl;
-      __syncthreads(); /* block-uniform: the outer loop bound and the slot flags are uniform */
-      /* ---- phase 2 ---- */
-      for (uint32_t t = lane; t < (a.ablate == 4 ? 0u : total); t += 64) {
-        /* source lane: the first one whose inclusive prefix exceeds t */
-        int lo = 0, hi = 63;
+      if (lane == 63) s_w[1][wave] = incl;
+      __syncthreads();
+      uint32_t woff = 0, total = 0;
 #pragma unroll
-        for (int it = 0; it < 6; ++it) {
+      for (int w = 0; w < RENDER_WAVES; ++w) {
+        uint32_t c = s_w[1][w];
+        if (w < wave) woff += c;
+        total += c;
+      }
+      s_incl[threadIdx.x] = incl + woff;
+      __syncthreads();
+      /* ---- phase 2 ---- */
+      for (uint32_t t = threadIdx.x; t < total; t += RENDER_THREADS) {
+        /* source record: the first one whose inclusive prefix exceeds t */
+        int lo = 0, hi = RENDER_THREADS - 1;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
           int mid = (lo + hi) >> 1;
-          if (s_incl[wbase + mid] > t)
+          if (s_incl[mid] > t)
             hi = mid;
           else
             lo = mid + 1;
         }
         const int src = lo;
-        const uint32_t excl = src ? s_incl[wbase + src - 1] : 0u;
-        const int32_t* r = s_rec[wbase + src];
+        const uint32_t excl = src ? s_incl[src - 1] : 0u;
+        const int32_t* r = s_rec[src];
         const uint32_t q = t - excl, w = (uint32_t)r[14];
         const uint32_t qj = q / w, qi = q - qj * w;
         const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
@@ -273,13 +327,12 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
           vt[k].tu = (k & 1) ? 1.0f : -1.0f;
           vt[k].tv = (k & 2) ? 1.0f : -1.0f;
         }
-        const uint32_t id = blk0 + (uint32_t)(wbase + src);
+        const uint32_t id = (uint32_t)r[15];
         /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
-        if (a.ablate == 5) { if (pi + pj + vt[3].X == 123456789) slot.zbuf[0] = id; continue; }
-        raster_pixel(vt[0], vt[1], vt[2], pi, pj, a.q.W, slot.zbuf, id, slot.tie, a.ablate);
-        raster_pixel(vt[2], vt[1], vt[3], pi, pj, a.q.W, slot.zbuf, id, slot.tie, a.ablate);
+        raster_pixel(vt[0], vt[1], vt[2], pi, pj, a.q.W, slot.zbuf, id, slot.tie);
+        raster_pixel(vt[2], vt[1], vt[3], pi, pj, a.q.W, slot.zbuf, id, slot.tie);
       }
-      __syncthreads(); /* s_rec / s_incl are reused by the next slot / iteration */
+      __syncthreads(); /* the LDS lists are reused by the next slot / iteration */
     }
   }
 }
