@@ -144,7 +144,8 @@ __device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
 __global__ void __launch_bounds__(256)
     k8_radius(const float4* __restrict__ V, const float4* __restrict__ N, float4* __restrict__ radius_conf,
               uint8_t* __restrict__ integrated, uint32_t P, float pixel_size, float angle_thresh, float min_radius,
-              float max_radius, DevState* ds, float* poses, float* poses_inv, uint32_t pose_idx, m4 pose) {
+              float max_radius, DevState* ds, float* poses, float* poses_inv, uint32_t pose_idx, m4 pose,
+              const float4* __restrict__ Sem, float4* __restrict__ pixrec) {
   uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= P) return;
   if (pix == 0) { /* per-update counters + SurfelMap.cpp:494-495: poses_[timestamp_] = pose */
@@ -172,6 +173,13 @@ __global__ void __launch_bounds__(256)
   }
   radius_conf[pix] = f4(radius, 0.0f, 0.0f, valid); /* quirk B-3: the confidence channel stays 0 */
   integrated[pix] = 0;
+  /* everything K9 gathers for a measurement pixel, packed into ONE 64-byte line (vertex, normal,
+   * label, label probability, radius): a surfel update then costs one random line instead of four */
+  const float4 sem = Sem[pix];
+  float4* r = pixrec + 4 * (size_t)pix;
+  r[0] = v;
+  r[1] = n;
+  r[2] = f4(sem.x, sem.w, radius, 0.0f);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -190,6 +198,7 @@ struct UpdArgs {
   uint32_t epoch;
   const float4 *V, *N, *Sem;
   const float4* radius_conf;
+  const float4* pixrec; /* packed K9 gather record, 4 x float4 per pixel (3 used) */
   uint8_t* integrated;
   uint32_t* index_map;
   proj_t q;
@@ -299,11 +308,14 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
   /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
   const bool in_tex = (imx >= 0.0f && imx < a.q.width && imy >= 0.0f && imy < a.q.height);
   const int32_t tx = in_tex ? (int32_t)sdm_floor(imx) : -1, ty = in_tex ? (int32_t)sdm_floor(imy) : -1;
-  /* all five gathers of this measurement pixel are issued together (semantic, radius and the K7
-   * winner are only needed on some paths, but fetching them now removes two dependent round trips) */
-  const float4 dv = texel(a.V, W, H, tx, ty), dn = texel(a.N, W, H, tx, ty);
-  const float4 ds = texel(a.Sem, W, H, tx, ty), rc = texel(a.radius_conf, W, H, tx, ty);
-  const unsigned long long k7key = a.zbuf[(size_t)max(ty, 0) * W + (size_t)max(tx, 0)];
+  /* one 64-byte line per measurement pixel (built by K8): vertex, normal, (label, prob, radius);
+   * border (0) outside the image or for NaN coordinates, as the NEAREST / CLAMP_TO_BORDER fetch */
+  const size_t rpix = (size_t)max(ty, 0) * W + (size_t)max(tx, 0);
+  const float4* __restrict__ rec = a.pixrec + 4 * rpix;
+  float4 dv = rec[0], dn = rec[1], dx = rec[2];
+  if (!in_tex) dv = dn = dx = f4(0.f, 0.f, 0.f, 0.f);
+  const float4 ds = f4(dx.x, 0.f, 0.f, dx.y), rc = f4(dx.z, 0.f, 0.f, 0.f);
+  const unsigned long long k7key = a.zbuf[rpix];
   const bool valid = (dv.w > 0.5f) && (dn.w > 0.5f);
   /* quirk B-6: all(lessThan(img, dim)) && !all(lessThan(img, 0)) */
   const bool inside =
@@ -605,6 +617,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.N = f->map[SUMA_MAP_NORMAL];
   a.Sem = f->map[SUMA_MAP_SEMANTIC];
   a.radius_conf = c->radius_conf;
+  a.pixrec = c->pixrec;
   a.integrated = c->integrated;
   a.index_map = c->index_map;
   a.q = c->pd;
@@ -638,7 +651,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     ProfScope ps(c, "k8_radius", 48.0 * P);
     k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, c->radius_conf, c->integrated, P, c->mc.pixel_size,
                                                 c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds, c->poses,
-                                                c->poses_inv, c->timestamp, a.pose);
+                                                c->poses_inv, c->timestamp, a.pose, a.Sem, c->pixrec);
   }
   if (!k7_done) { /* otherwise the splat was fused into the post-ICP render pass (same pose, same map) */
     ProfScope ps(c, "k7_indexmap", 64.0 * S + 8.0 * P);

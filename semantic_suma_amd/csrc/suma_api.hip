@@ -254,6 +254,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->eroded, P * sizeof(float4)));
     CK(hipMalloc((void**)&c->radius_conf, P * sizeof(float4)));
     CK(hipMemsetAsync(c->radius_conf, 0, P * sizeof(float4), c->stream));
+    CK(hipMalloc((void**)&c->pixrec, P * 4 * sizeof(float4)));
     CK(hipMalloc((void**)&c->integrated, P));
     CK(hipMemsetAsync(c->integrated, 0, P, c->stream));
     CK(hipMalloc((void**)&c->index_map, P * 4));
@@ -322,7 +323,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.b);
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
-  void* dev[] = {c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
+  void* dev[] = {c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
                  c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs};

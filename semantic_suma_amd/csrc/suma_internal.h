@@ -116,6 +116,7 @@ struct suma_ctx {
   suma_frame *old_frame, *new_frame, *composed_frame;
   unsigned long long *zbuf_a, *zbuf_b; /* Pm */
   float4* radius_conf;                 /* P */
+  float4* pixrec;                      /* P x 4: packed measurement record for K9 (one 64-byte line per pixel) */
   uint8_t* integrated;                 /* P */
   uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
   unsigned long long* tile_status;     /* look-back status words */
