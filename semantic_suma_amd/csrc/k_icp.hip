@@ -27,8 +27,6 @@
  *     (19 -> see profiles/).  State and partials are double buffered by launch parity; block 0
  *     writes the state.  The next iteration is just the next launch: no host round trip.
  */
-#include <cstdlib>
-
 #include "suma_internal.h"
 
 #define ICP_THREADS 512 /* 8 waves per block, one block per CU: 131072 lanes = one 64x2048 image in flight */

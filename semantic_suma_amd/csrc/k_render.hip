@@ -25,7 +25,6 @@
  *   - the resolve pass gathers the winning surfel's attributes, applies K5 and leaves the
  *     z-buffers cleared for the next render (no separate clear launch).
  */
-#include <cstdlib>
 #include <cstring>
 
 #include "suma_internal.h"
@@ -54,7 +53,6 @@ struct RenderArgs {
   int k7_enabled;
   proj_t k7_q;
   unsigned long long* k7_zbuf;
-  int ablate; /* debug only (SUMA_RENDER_ABLATE) */
 };
 
 struct rvtx {
@@ -438,10 +436,6 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.k7_enabled = 0;
   a.k7_q = c->pd;
   a.k7_zbuf = c->zbuf_data;
-  {
-    const char* e = getenv("SUMA_RENDER_ABLATE");
-    a.ablate = e ? atoi(e) : 0;
-  }
   return a;
 }
 static uint32_t stream_grid(suma_ctx* c) {
