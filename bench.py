@@ -96,8 +96,16 @@ def main():
     scans = []
     t_gen = time.perf_counter()
     E = 0 if args.no_kernel_events else max(0, min(args.profile_scans, K))
+    kitti_dir = os.environ.get("SUMA_KITTI_DIR")  # e.g. .../sequences/00 ; absent on the build / bench machines
+    seq = None
+    if kitti_dir:
+        from semantic_suma_amd import kitti
+        seq = kitti.Sequence(kitti_dir)
     for k in range(Wu + K + E):
-        pts, lab, prob, _ = synth.generate_scan(k0 + k, n_azimuth=W, height=H)
+        if seq is not None:
+            pts, lab, prob = seq[(k0 + k) % len(seq)]
+        else:
+            pts, lab, prob, _ = synth.generate_scan(k0 + k, n_azimuth=W, height=H)
         scans.append((ctx.device_array(pts), ctx.device_array(lab), ctx.device_array(prob), pts.shape[0],
                       (pts, lab, prob) if (rank == 0 and k < args.cpu_scans) else None))
     t_gen = time.perf_counter() - t_gen
@@ -151,7 +159,7 @@ def main():
     out = {
         "metric": "scans_per_sec", "value": world * K / elapsed, "unit": "scans/s", "n_gpus": world, "steps": K,
         "warmup": Wu, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "kitti" if seq is not None else "synthetic",
         "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-like sequence, {H}x{W} range images, "
                                f"semantic-weighted ICP ({args.icp_iterations} GN iterations + stats pass) + surfel "
                                "fusion, one sequence per GPU, scans resident in HBM",

@@ -1,0 +1,89 @@
+"""KITTI odometry input: the formats the reference's readers consume, as numpy.
+
+  velodyne/NNNNNN.bin   N x 4 float32 little-endian (x, y, z, remission) -- reference
+                        src/io/KITTIReader.cpp:140-167 turns each row into rv::Point3f (x, y, z, 1)
+  labels/NNNNNN.label   N x uint32 SemanticKITTI labels (lower 16 bits = class id); stands in for the
+                        RangeNet++ inference of src/io/KITTIReader.cpp:175-200, which produces a class id
+                        per point (labels_float) and its softmax probability (labels_prob)
+  calib.txt / poses     src/util/kitti_utils.cpp:32-61 (P0..P3, Tr); poses are written in the camera frame
+                        (src/visualizer/VisualizerWindow.cpp:848-872): pose_cam = Tr * pose_velo * Tr^-1
+
+No dataset ships with this repository and the build machines have no network: `bench.py` uses these
+readers only when SUMA_KITTI_DIR points at `sequences/XX`.
+"""
+from __future__ import annotations
+
+import glob
+import os
+
+import numpy as np
+
+
+def read_velodyne(path: str) -> np.ndarray:
+    """-> points[N, 4] float32 (x, y, z, 1) as rv::Point3f"""
+    raw = np.fromfile(path, dtype="<f4")
+    if raw.size % 4:
+        raise ValueError(f"{path}: size is not a multiple of 4 floats")
+    pts = raw.reshape(-1, 4).copy()
+    pts[:, 3] = 1.0
+    return pts
+
+
+def read_labels(path: str, n_points: int, prob: float = 1.0):
+    """SemanticKITTI .label -> (labels_float[N], labels_prob[N]); ground-truth labels carry probability `prob`"""
+    raw = np.fromfile(path, dtype="<u4")
+    if raw.size != n_points:
+        raise ValueError(f"{path}: {raw.size} labels for {n_points} points")
+    cls = (raw & 0xFFFF).astype(np.float32)
+    # moving classes 252..259 of SemanticKITTI map onto their static ids, as RangeNet++'s learning map does
+    moving = {252: 10, 253: 31, 254: 30, 255: 32, 256: 16, 257: 13, 258: 18, 259: 20}
+    for k, v in moving.items():
+        cls[cls == k] = v
+    return cls, np.full(n_points, prob, dtype=np.float32)
+
+
+def read_calib(path: str) -> dict:
+    """kitti_utils.cpp:32-61: 'P0: ...' lines of 12 floats -> 4x4 matrices (last row 0 0 0 1)"""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            if ":" not in line:
+                continue
+            key, vals = line.split(":", 1)
+            v = np.array(vals.split(), dtype=np.float64)
+            if v.size == 12:
+                M = np.eye(4)
+                M[:3, :4] = v.reshape(3, 4)
+                out[key.strip()] = M
+    return out
+
+
+def poses_to_camera_frame(poses_velo, Tr: np.ndarray) -> np.ndarray:
+    """VisualizerWindow.cpp:848-872: pose_cam = Tr * pose_velo * Tr^-1, flattened to the 12-value KITTI rows"""
+    Tinv = np.linalg.inv(Tr)
+    return np.stack([(Tr @ np.asarray(P) @ Tinv)[:3, :4].reshape(12) for P in poses_velo])
+
+
+class Sequence:
+    """one `sequences/XX` directory"""
+
+    def __init__(self, root: str):
+        self.root = root
+        self.scans = sorted(glob.glob(os.path.join(root, "velodyne", "*.bin")))
+        if not self.scans:
+            raise FileNotFoundError(f"no velodyne/*.bin under {root}")
+        calib = os.path.join(root, "calib.txt")
+        self.calib = read_calib(calib) if os.path.exists(calib) else {}
+
+    def __len__(self):
+        return len(self.scans)
+
+    def __getitem__(self, k: int):
+        pts = read_velodyne(self.scans[k])
+        lab_path = os.path.join(self.root, "labels", os.path.basename(self.scans[k]).replace(".bin", ".label"))
+        if os.path.exists(lab_path):
+            labels, probs = read_labels(lab_path, pts.shape[0])
+        else:
+            labels = np.zeros(pts.shape[0], np.float32)
+            probs = np.zeros(pts.shape[0], np.float32)
+        return pts, labels, probs
