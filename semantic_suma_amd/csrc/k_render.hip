@@ -377,6 +377,10 @@ struct ResolveArgs {
   float4 *va, *na, *sa; /* targets of zbuf_a (old frame / single target); NULL = not written */
   float4 *vb, *nb, *sb; /* targets of zbuf_b (new frame) */
   float4 *vo, *no, *so; /* composed output (K5) */
+  /* optional mirror of target a (Frame::copy fused into the resolve): vertex / normal as written,
+   * semantic copied from sa_src (the semantic map is not re-rendered by render_active) */
+  float4 *vm, *nm, *sm;
+  const float4* sm_src;
 };
 
 /* single z-buffer -> up to three maps */
@@ -389,6 +393,11 @@ __global__ void __launch_bounds__(256) k_resolve(ResolveArgs a) {
   if (a.va) a.va[pix] = o.v;
   if (a.na) a.na[pix] = o.n;
   if (a.sa) a.sa[pix] = o.s;
+  if (a.vm) {
+    a.vm[pix] = o.v;
+    a.nm[pix] = o.n;
+    a.sm[pix] = a.sm_src[pix];
+  }
 }
 
 /* old + new z-buffers -> old frame, new frame and the K5 composition (render_compose.frag:26-48) */
@@ -470,7 +479,9 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
   if (c->p.compose_rendering) {
     int32_t thr = (int32_t)(c->timestamp - 100u); /* SurfelMap.cpp:873, quirk B-7 */
     RenderArgs a = render_args(c, conf_threshold, thr);
-    a.slot[0].enabled = 1;
+    /* "old" surfels have creation stamp < thr: none can exist while thr <= 0 (the first 100 scans,
+     * quirk B-7), so the pass is skipped; its z-buffer stays empty and resolves to the cleared frame */
+    a.slot[0].enabled = thr > 0 ? 1 : 0;
     a.slot[0].mode = 0;
     a.slot[0].tie = TIE_LOW_INDEX;
     a.slot[0].zbuf = c->zbuf_a;
@@ -535,7 +546,8 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
 /* render_active (which = 1, SurfelMap.cpp:1023-1069) / render_inactive (which = 0, :1071-1114).
  * Only COLOR0 / COLOR1 are re-attached (:1047-1048): the semantic map of the target frame is NOT
  * refreshed by these calls; restated as such. */
-hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7) {
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7,
+                                    suma_frame* mirror) {
   float inv[16];
   rigid_inverse_f(pose, inv);
   int32_t thr = (int32_t)(c->timestamp - 100u);
@@ -558,8 +570,14 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   r.va = tgt->map[0];
   r.na = tgt->map[1];
   r.sa = nullptr;
+  if (mirror) { /* lastModelFrame_->copy(*map_->newMapFrame()), SurfelMapping.cpp:407, without a second pass */
+    r.vm = mirror->map[0];
+    r.nm = mirror->map[1];
+    r.sm = mirror->map[2];
+    r.sm_src = tgt->map[2];
+  }
   {
-    ProfScope ps(c, "k5_resolve", (8.0 + 32.0) * (double)c->Pm);
+    ProfScope ps(c, "k5_resolve", (8.0 + 32.0 + (mirror ? 64.0 : 0.0)) * (double)c->Pm);
     k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->stream>>>(r);
   }
   return hipGetLastError();

@@ -705,13 +705,13 @@ extern "C" int suma_map_render(suma_ctx* c, const float pose_old[16], const floa
 extern "C" int suma_map_render_active(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
   c->rendered.valid = false;
-  CK(launch_map_render_single(c, pose, conf_threshold, 1, 0));
+  CK(launch_map_render_single(c, pose, conf_threshold, 1, 0, nullptr));
   return SUMA_OK;
 }
 extern "C" int suma_map_render_inactive(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
   c->rendered.valid = false;
-  CK(launch_map_render_single(c, pose, conf_threshold, 0, 0));
+  CK(launch_map_render_single(c, pose, conf_threshold, 0, 0, nullptr));
   return SUMA_OK;
 }
 extern "C" int suma_map_render_composed(suma_ctx* c, const float pose_old[16], const float pose_new[16],
@@ -993,13 +993,12 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   c->rendered.valid = false; /* NEW is re-rendered from the ICP pose */
   /* updateMap() will build the index map (K7) from this very pose unless the fallback ICP changes
    * it: fuse the splat into this pass over the surfels */
-  CK(launch_map_render_single(c, posef, conf_threshold(s), 1, 1));         /* :406 */
+  /* ... and lastModelFrame_->copy(newMapFrame) (:407) is written by the same resolve pass */
+  CK(launch_map_render_single(c, posef, conf_threshold(s), 1, 1, s->last_model)); /* :406-407 */
   c->k7.valid = true;
   c->k7.map_version = c->map_version;
   c->k7.params_version = c->params_version;
   memcpy(c->k7.pose, posef, sizeof(posef));
-  r = suma_frame_copy(c, s->last_model, c->new_frame);                     /* :407 */
-  if (r) return r;
   eye_d(I);
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;

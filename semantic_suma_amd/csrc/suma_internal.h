@@ -213,7 +213,8 @@ const GnState* gn_result(suma_ctx* c);
 /* k_render.hip */
 hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
                              suma_frame* out);
-hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7);
+hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7,
+                                    suma_frame* mirror);
 hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
                                       float conf_threshold);
 /* k_update.hip */
