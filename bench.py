@@ -148,8 +148,11 @@ def main():
             pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
         kernels = ctx.profile_get()
     ctx.profile(0)
-    gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + Wu + K - 1)
-    drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
+    if seq is None:  # synthetic trajectory: known ground truth
+        gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + Wu + K - 1)
+        drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
+    else:
+        drift = float("nan")
 
     if rank != 0:
         if world > 1:
