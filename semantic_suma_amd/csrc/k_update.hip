@@ -49,14 +49,17 @@ __device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, uint32_t f
  * on words that are not published yet.  Critical path = compute + one publish + one read.
  * Status words carry the launch epoch (never cleared); group accumulators are cleared by the
  * finaliser of each launch (block_leaves_last). */
-__device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
-                                    uint32_t tile, uint32_t ntiles, uint32_t agg, uint32_t epoch, int lane) {
+__device__ __forceinline__ void lookback_publish(unsigned long long* __restrict__ status,
+                                                 unsigned long long* __restrict__ group, uint32_t tile, uint32_t agg,
+                                                 uint32_t epoch) {
+  __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(&group[tile >> 6], (1ull << 32) | (unsigned long long)agg, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+}
+/* called by one full wave; returns the number of selected items in all tiles before `tile` */
+__device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
+                                     uint32_t tile, uint32_t epoch, int lane) {
   const uint32_t g = tile >> 6;
-  if (lane == 0) {
-    __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(&group[g], (1ull << 32) | (unsigned long long)agg, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-  }
   uint32_t sum = 0;
   /* complete groups before mine: every group before g holds exactly 64 tiles */
   for (uint32_t gi = lane; gi < g; gi += 64) {
@@ -75,10 +78,15 @@ __device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, uns
     } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
     sum += (uint32_t)(w & 0xffffffffull);
   }
-  (void)ntiles;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
   return sum;
+}
+__device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
+                                    uint32_t tile, uint32_t ntiles, uint32_t agg, uint32_t epoch, int lane) {
+  (void)ntiles;
+  if (lane == 0) lookback_publish(status, group, tile, agg, epoch);
+  return lookback_collect(status, group, tile, epoch, lane);
 }
 
 /* block-level stable ranking of a flag: returns the rank of this thread among the block's
@@ -419,60 +427,106 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
 
 /* K9 (+ K11 predicate): single-pass update with stable compaction.  Tiles of 256 surfels are
  * handed out by ticket; output offset by decoupled look-back. */
+/* Tiles are processed in PAIRS per block: compute tile A (survivors staged in LDS, count published),
+ * compute tile B (same), and only then wait for A's output offset, stream A out, wait for B's, stream
+ * B out.  A tile's offset depends on every earlier tile of the launch having published its count, so
+ * waiting right after the compute exposes each block to the slowest of the ~256 tiles in flight
+ * ahead of it (head-of-line blocking, 24 us per tile independent of occupancy); with the wait
+ * deferred behind the next tile's compute it is almost always already satisfied.  A block never
+ * waits before it has published the counts of both of its tiles, so there is no circular wait.
+ * The LDS staging also turns the 64-byte-strided record stores into a dense 16 B-per-lane stream. */
+#define K9_PAIR 2u
 __global__ void __launch_bounds__(SUMA_TILE) k9_update(UpdArgs a) {
-  __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES];
-  __shared__ uint32_t s_prefix;
+  __shared__ float4 s_out[K9_PAIR][SUMA_TILE][4];
+  __shared__ uint32_t s_cnt_emit[TILE_WAVES], s_cnt_keep[TILE_WAVES];
+  __shared__ uint32_t s_tile, s_prefix;
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
+  const uint32_t npairs = (ntiles + K9_PAIR - 1) / K9_PAIR; /* tickets are handed out per pair */
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
+  float4* __restrict__ dst4 = reinterpret_cast<float4*>(a.out);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_count = 0; /* thread 0: survivors before the area filter (S') */
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0)
       s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    const uint32_t tile = s_tile;
-    if (tile >= ntiles) break;
-    const uint32_t i = tile * SUMA_TILE + threadIdx.x;
-    bool keep = false, emit = false;
-    Surfel4 o;
-    if (i < S) {
-      Surfel4 in;
-      in.a = sf[4 * (size_t)i];
-      in.b = sf[4 * (size_t)i + 1];
-      in.c = sf[4 * (size_t)i + 2];
-      in.d = sf[4 * (size_t)i + 3];
-      int32_t mark_pix;
-      keep = update_one(a, i, in, o, &mark_pix);
-      if (mark_pix >= 0) a.integrated[mark_pix] = 1;
-      emit = keep && in_active_area(a, o);
+    const uint32_t pair = s_tile;
+    if (pair >= npairs) break;
+    uint32_t total[K9_PAIR];
+#pragma unroll 1
+    for (uint32_t h = 0; h < K9_PAIR; ++h) {
+      const uint32_t tile = pair * K9_PAIR + h;
+      total[h] = 0;
+      if (tile >= ntiles) break; /* block-uniform */
+      const uint32_t i = tile * SUMA_TILE + threadIdx.x;
+      bool keep = false, emit = false;
+      Surfel4 o;
+      if (i < S) {
+        Surfel4 in;
+        in.a = sf[4 * (size_t)i];
+        in.b = sf[4 * (size_t)i + 1];
+        in.c = sf[4 * (size_t)i + 2];
+        in.d = sf[4 * (size_t)i + 3];
+        int32_t mark_pix;
+        keep = update_one(a, i, in, o, &mark_pix);
+        if (mark_pix >= 0) a.integrated[mark_pix] = 1;
+        emit = keep && in_active_area(a, o);
+      }
+      const unsigned long long kb = __ballot(keep), eb = __ballot(emit);
+      if (lane == 0) {
+        s_cnt_keep[wave] = __popcll(kb); /* S' statistics (parity with the reference's TF count) */
+        s_cnt_emit[wave] = __popcll(eb);
+      }
+      __syncthreads();
+      uint32_t off = 0, tot = 0, kc = 0;
+#pragma unroll
+      for (int w = 0; w < (int)TILE_WAVES; ++w) {
+        const uint32_t cnt = s_cnt_emit[w];
+        if (w < wave) off += cnt;
+        tot += cnt;
+        kc += s_cnt_keep[w];
+      }
+      total[h] = tot;
+      if (threadIdx.x == 0) keep_count += kc;
+      if (emit) { /* stage at the block-local compacted position */
+        const uint32_t r = off + __popcll(eb & ((1ull << lane) - 1ull));
+        s_out[h][r][0] = o.a;
+        s_out[h][r][1] = o.b;
+        s_out[h][r][2] = o.c;
+        s_out[h][r][3] = o.d;
+      }
+      /* publish the count now; the offset is collected later */
+      if (threadIdx.x == 0) lookback_publish(a.status, a.group, tile, tot, a.epoch);
+      __syncthreads(); /* s_cnt_* are reused by the next tile of the pair */
     }
-    /* S' statistics (parity with the reference's transform-feedback count) */
-    {
-      const unsigned long long kb = __ballot(keep);
-      if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(kb);
-    }
-    BlockRank br = block_rank(emit, s_wave_a); /* contains a __syncthreads */
-    if (threadIdx.x == 0)
-      for (int w = 0; w < (int)TILE_WAVES; ++w) keep_count += s_wave_b[w];
-    if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
-      if (threadIdx.x == 0) s_prefix = pre;
-    }
-    __syncthreads();
-    if (emit) {
-      uint32_t dst = s_prefix + br.rank;
-      if (dst < a.max_surfels) store_surfel(a.out, dst, o);
-    }
-    if (tile == ntiles - 1 && threadIdx.x == 0) {
-      uint32_t total = s_prefix + br.total;
-      a.ds->n_kept_updated = total < a.max_surfels ? total : a.max_surfels;
+#pragma unroll 1
+    for (uint32_t h = 0; h < K9_PAIR; ++h) {
+      const uint32_t tile = pair * K9_PAIR + h;
+      if (tile >= ntiles) break;
+      if (threadIdx.x < 64) {
+        uint32_t pre = lookback_collect(a.status, a.group, tile, a.epoch, threadIdx.x);
+        if (threadIdx.x == 0) s_prefix = pre;
+      }
+      __syncthreads();
+      const uint32_t prefix = s_prefix;
+      /* compacted stream-out: chunk c = (rank, 16-byte part) */
+      const float4* __restrict__ src = &s_out[h][0][0];
+      for (uint32_t c = threadIdx.x; c < 4u * total[h]; c += SUMA_TILE) {
+        const uint64_t d = 4ull * prefix + c;
+        if (d < 4ull * a.max_surfels) dst4[d] = src[c];
+      }
+      if (tile == ntiles - 1 && threadIdx.x == 0) {
+        uint32_t tot = prefix + total[h];
+        a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
+      }
+      __syncthreads(); /* s_prefix is reused */
     }
   }
   if (threadIdx.x == 0 && keep_count)
     __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (is_finaliser(s_tile, ntiles)) {
+  if (is_finaliser(s_tile, npairs)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
     if (threadIdx.x == 0 && ntiles == 0) a.ds->n_kept_updated = 0;
   }
@@ -662,7 +716,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     a.epoch = ++c->epoch;
     a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
     a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
-    k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), SUMA_TILE, 0, st>>>(a);
+    k9_update<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + 1) / 2), SUMA_TILE, 0, st>>>(a);
   }
   {
     ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);
