@@ -239,44 +239,59 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
         corner[1] = sub3(add3(cp, ru), rv);
         corner[2] = add3(sub3(cp, ru), rv);
         corner[3] = add3(add3(cp, ru), rv);
+        /* The spherical projection of the corners is evaluated in two halves: first range + pitch
+         * (image row), and the yaw (atan2, image column) only if the rows spanned by the quad contain
+         * a pixel-centre row at all -- at 64 rows over 28 degrees about half of the quads do not.
+         * Identical values to project01(), just not computed when they cannot matter. */
         int32_t X[4], Y[4];
         float Z[4];
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          v3 pr = project01(a.q, corner[k]);
-          /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
-          if (cppx - pr.x > 0.5f) pr.x += 1.0f;
-          if (pr.x - cppx > 0.5f) pr.x -= 1.0f;
-          float xw = pr.x * a.q.width, yw = pr.y * a.q.height;
-          if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = true;
-          X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
+          const float depth = len3(corner[k]);
+          const float pitch = -sdm_asin(corner[k].z / depth);
+          const float y01 = 1.0f - ((pitch * SUMA_RAD2DEG_F) + a.q.fov_up) / a.q.fov;
+          Z[k] = (depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth);
+          const float yw = y01 * a.q.height;
+          if (sdm_isnan(yw) || sdm_isnan(Z[k])) bad = true;
           Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
-          Z[k] = pr.z;
         }
-        if (!bad) {
-          const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
-          const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
-          int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel centres inside the box */
-          int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8;
-          i0 = max(i0, 0);
-          j0 = max(j0, 0);
-          i1 = min(i1, a.q.W - 1);
-          j1 = min(j1, a.q.H - 1);
-          if (i0 <= i1 && j0 <= j1) {
-            const int32_t w = i1 - i0 + 1;
-            ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
-            int32_t* q = s_rec[threadIdx.x];
+        const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
+        int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8; /* pixel-centre rows inside the box */
+        j0 = max(j0, 0);
+        j1 = min(j1, a.q.H - 1);
+        if (!bad && j0 <= j1) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              q[k] = X[k];
-              q[4 + k] = Y[k];
-              q[8 + k] = __float_as_int(Z[k]);
+          for (int k = 0; k < 4; ++k) {
+            const float yaw = sdm_atan2(corner[k].y, corner[k].x);
+            float x01 = 0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f);
+            /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
+            if (cppx - x01 > 0.5f) x01 += 1.0f;
+            if (x01 - cppx > 0.5f) x01 -= 1.0f;
+            const float xw = x01 * a.q.width;
+            if (sdm_isnan(xw)) bad = true;
+            X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
+          }
+          if (!bad) {
+            const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
+            int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel-centre columns inside the box */
+            i0 = max(i0, 0);
+            i1 = min(i1, a.q.W - 1);
+            if (i0 <= i1) {
+              const int32_t w = i1 - i0 + 1;
+              ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
+              int32_t* q = s_rec[threadIdx.x];
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                q[k] = X[k];
+                q[4 + k] = Y[k];
+                q[8 + k] = __float_as_int(Z[k]);
+              }
+              q[12] = i0;
+              q[13] = j0;
+              q[14] = w;
+              q[15] = __float_as_int(r[8]);
             }
-            q[12] = i0;
-            q[13] = j0;
-            q[14] = w;
-            q[15] = __float_as_int(r[8]);
           }
         }
       }
