@@ -11,7 +11,7 @@
  *   K3 Preprocessing.cpp:281-327 + floodfill.frag:34-84     (label flood fill)
  *
  * Layout: every map is a row-major W x H array of float4 (row 0 = lowest beam); one thread per
- * texel, 16 B per lane, a wave covers 1 KiB of one row.
+ * texel, 16 B per lane.  K2 + K3 run as ONE kernel over LDS-staged tiles (k23_normals_labels).
  */
 #include "suma_internal.h"
 
@@ -73,82 +73,118 @@ __device__ __forceinline__ int32_t wrapx(int32_t x, int32_t w) {
   return x;
 }
 
-__global__ void __launch_bounds__(256)
-    k2_normals(const float4* __restrict__ V, const float4* __restrict__ S, float4* __restrict__ normal,
-               float4* __restrict__ eroded, int32_t W, int32_t H) {
-  int32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t y = blockIdx.y;
-  if (x >= W) return;
-  size_t pix = (size_t)y * W + x;
-  float4 nrm = f4(0.f, 0.f, 0.f, 1.f);
-  float4 ero = f4(0.f, 0.f, 0.f, 1.f);
-  float4 p = V[pix];
-  if (p.w > 0.0f) {
-    nrm.w = 1.0f;
-    int32_t xp = wrapx(x + 1, W), xm = wrapx(x - 1, W);
-    float4 u = texel(V, W, H, xp, y);
-    float4 v = texel(V, W, H, x, y + 1);
-    float4 s = texel(V, W, H, xm, y);
-    float4 t = texel(V, W, H, x, y - 1);
-    v3 pp = xyz(p);
-    v3 un = normalize3(sub3(xyz(u), pp));
-    v3 vn = normalize3(sub3(xyz(v), pp));
-    if (u.w < 1.0f && v.w < 1.0f) nrm.w = 0.0f;
-    if (s.w < 1.0f && t.w < 1.0f) nrm.w = 0.0f;
-    if (!(u.w > 0.5f) || !(v.w > 0.5f)) nrm.w = 0.0f;
+/* K2 + K3 fused over LDS tiles.  A block owns a PRE_TX x PRE_TY patch of the image and stages the
+ * vertex and semantic maps of the patch plus a halo of 3 texels (x wraps around the 360-degree
+ * image, rows outside the image are the zero border) in LDS: the 5-point normal / erosion stencil
+ * needs +-1, the flood fill reads ERODED labels at +-1 / +-2, and erosion itself looks one further.
+ * Stage B writes the normal map and keeps the eroded labels of patch + halo 2 in LDS, stage C does
+ * the flood fill from LDS -- the intermediate "eroded" image never exists in HBM and the per-texel
+ * neighbour fetches (9 vertex + 13 label reads) are LDS reads. */
+#define PRE_TX 64
+#define PRE_TY 8
+#define PRE_H3 3
+#define PRE_SW (PRE_TX + 2 * PRE_H3) /* 70 */
+#define PRE_SH (PRE_TY + 2 * PRE_H3) /* 14 */
+#define PRE_EW (PRE_TX + 4)          /* eroded: halo 2 */
+#define PRE_EH (PRE_TY + 4)
 
-    /* erosion, kernel_size 2 -> offset 1 (gen_normalmap.frag:69-85) */
-    float4 sp = S[pix];
-    ero = sp;
-    float pl = sp.x;
-    float ul = texel(S, W, H, xp, y).x;
-    float vl = texel(S, W, H, x, y + 1).x;
-    float sl = texel(S, W, H, xm, y).x;
-    float tl = texel(S, W, H, x, y - 1).x;
-    if ((pl != ul && ul != 0.0f) || (pl != vl && vl != 0.0f) || (pl != sl && sl != 0.0f) || (pl != tl && tl != 0.0f))
-      ero = f4(0.f, 0.f, 0.f, 1.f);
-
-    if (nrm.w > 0.0f) {
-      v3 w = cross3(un, vn);
-      float len = len3(w);
-      nrm = f4(w.x / len, w.y / len, w.z / len, (len > 0.0000001f) ? 1.0f : 0.0f);
+__global__ void __launch_bounds__(PRE_TX* PRE_TY)
+    k23_normals_labels(const float4* __restrict__ V, const float4* __restrict__ S, float4* __restrict__ normal,
+                       float4* __restrict__ refined, int32_t W, int32_t H) {
+  __shared__ float4 sV[PRE_SH][PRE_SW];
+  __shared__ float4 sS[PRE_SH][PRE_SW];
+  __shared__ float4 sE[PRE_EH][PRE_EW];
+  const int32_t x0 = blockIdx.x * PRE_TX, y0 = blockIdx.y * PRE_TY;
+  const int tid = threadIdx.x;
+  /* ---- stage A: patch + halo 3 ---- */
+  for (int t = tid; t < PRE_SW * PRE_SH; t += PRE_TX * PRE_TY) {
+    const int ly = t / PRE_SW, lx = t - ly * PRE_SW;
+    int32_t gx = x0 + lx - PRE_H3, gy = y0 + ly - PRE_H3;
+    if (gx >= W) gx -= W; /* gen_normalmap.frag:24-32 wrap() */
+    if (gx < 0) gx += W;
+    /* a patch that overhangs the right image edge (W not a multiple of the tile) may wrap twice */
+    if (gx >= W) gx -= W;
+    float4 v = f4(0.f, 0.f, 0.f, 0.f), s = v;
+    if (gy >= 0 && gy < H) {
+      v = V[(size_t)gy * W + gx];
+      s = S[(size_t)gy * W + gx];
     }
+    sV[ly][lx] = v;
+    sS[ly][lx] = s;
   }
-  normal[pix] = nrm;
-  eroded[pix] = ero;
-}
-
-__global__ void __launch_bounds__(256)
-    k3_floodfill(const float4* __restrict__ V, const float4* __restrict__ E, float4* __restrict__ refined, int32_t W,
-                 int32_t H) {
-  int32_t x = blockIdx.x * blockDim.x + threadIdx.x;
-  int32_t y = blockIdx.y;
-  if (x >= W) return;
-  size_t pix = (size_t)y * W + x;
-  const float threshold = 0.007f;
-  float4 out = E[pix];
-  float plabel = out.x;
-  if (plabel == 0.0f) { /* only unlabeled texels can change (floodfill.frag:52) */
-    float lp = len3(xyz(V[pix]));
-    bool hit = false;
-    for (int32_t offset = 1; offset < 3 && !hit; ++offset) {
-      const int32_t nx[4] = {wrapx(x + offset, W), x, wrapx(x - offset, W), x};
-      const int32_t ny[4] = {y, y + offset, y, y - offset};
+  __syncthreads();
+  /* ---- stage B: eroded labels for patch + halo 2 (gen_normalmap.frag:69-85) ---- */
+  for (int t = tid; t < PRE_EW * PRE_EH; t += PRE_TX * PRE_TY) {
+    const int ey = t / PRE_EW, ex = t - ey * PRE_EW;
+    const int ly = ey + 1, lx = ex + 1; /* position in the halo-3 arrays */
+    const int32_t gy = y0 + ey - 2;
+    float4 ero = f4(0.f, 0.f, 0.f, 0.f); /* outside the image: the sampler's border colour */
+    if (gy >= 0 && gy < H) {
+      ero = f4(0.f, 0.f, 0.f, 1.f);
+      if (sV[ly][lx].w > 0.0f) {
+        const float4 sp = sS[ly][lx];
+        ero = sp;
+        const float pl = sp.x;
+        const float ul = sS[ly][lx + 1].x, vl = sS[ly + 1][lx].x, sl = sS[ly][lx - 1].x, tl = sS[ly - 1][lx].x;
+        if ((pl != ul && ul != 0.0f) || (pl != vl && vl != 0.0f) || (pl != sl && sl != 0.0f) || (pl != tl && tl != 0.0f))
+          ero = f4(0.f, 0.f, 0.f, 1.f);
+      }
+    }
+    sE[ey][ex] = ero;
+  }
+  /* normals of the patch itself (gen_normalmap.frag:41-66, 87-99) */
+  const int px = tid % PRE_TX, py = tid / PRE_TX;
+  const int32_t gx = x0 + px, gy = y0 + py;
+  const bool inside = gx < W && gy < H;
+  {
+    const int ly = py + PRE_H3, lx = px + PRE_H3;
+    float4 nrm = f4(0.f, 0.f, 0.f, 1.f);
+    const float4 p = sV[ly][lx];
+    if (p.w > 0.0f) {
+      nrm.w = 1.0f;
+      const float4 u = sV[ly][lx + 1], v = sV[ly + 1][lx], s = sV[ly][lx - 1], t = sV[ly - 1][lx];
+      v3 pp = xyz(p);
+      v3 un = normalize3(sub3(xyz(u), pp));
+      v3 vn = normalize3(sub3(xyz(v), pp));
+      if (u.w < 1.0f && v.w < 1.0f) nrm.w = 0.0f;
+      if (s.w < 1.0f && t.w < 1.0f) nrm.w = 0.0f;
+      if (!(u.w > 0.5f) || !(v.w > 0.5f)) nrm.w = 0.0f;
+      if (nrm.w > 0.0f) {
+        v3 w = cross3(un, vn);
+        float len = len3(w);
+        nrm = f4(w.x / len, w.y / len, w.z / len, (len > 0.0000001f) ? 1.0f : 0.0f);
+      }
+    }
+    if (inside) normal[(size_t)gy * W + gx] = nrm;
+  }
+  __syncthreads();
+  /* ---- stage C: flood fill (floodfill.frag:34-84) ---- */
+  if (inside) {
+    const int ey = py + 2, ex = px + 2;
+    const int ly = py + PRE_H3, lx = px + PRE_H3;
+    const float threshold = 0.007f;
+    float4 out = sE[ey][ex];
+    if (out.x == 0.0f) { /* only unlabeled texels can change */
+      const float lp = len3(xyz(sV[ly][lx]));
+      bool hit = false;
+      for (int offset = 1; offset < 3 && !hit; ++offset) {
+        const int dx[4] = {offset, 0, -offset, 0}, dy[4] = {0, offset, 0, -offset};
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (hit) break;
-        float4 ql = texel(E, W, H, nx[k], ny[k]);
-        if (ql.x != 0.0f) {
-          float lq = len3(xyz(texel(V, W, H, nx[k], ny[k])));
-          if (sdm_abs(lp - lq) < threshold * lp) {
-            out = f4(ql.x, ql.y, ql.z, ql.w / (float)(offset + 1));
-            hit = true;
+        for (int k = 0; k < 4; ++k) {
+          if (hit) break;
+          const float4 ql = sE[ey + dy[k]][ex + dx[k]];
+          if (ql.x != 0.0f) {
+            const float lq = len3(xyz(sV[ly + dy[k]][lx + dx[k]]));
+            if (sdm_abs(lp - lq) < threshold * lp) {
+              out = f4(ql.x, ql.y, ql.z, ql.w / (float)(offset + 1));
+              hit = true;
+            }
           }
         }
       }
     }
+    refined[(size_t)gy * W + gx] = out;
   }
-  refined[pix] = out;
 }
 
 hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_labels, const float* d_probs, uint32_t n,
@@ -161,14 +197,15 @@ hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_la
     if (n > 0) k1_scatter<<<(n + 255) / 256, 256, 0, st>>>(d_pts, n, c->pd, c->zbuf_data);
     k1_resolve<<<(P + 255) / 256, 256, 0, st>>>(c->zbuf_data, d_pts, d_labels, d_probs, n, c->p.label_offset,
                                                  c->p.prob_offset, timestamp < 10 ? 1 : 0, out->map[SUMA_MAP_VERTEX],
-                                                 out->map[SUMA_MAP_SEMANTIC], P);
+                                                 c->eroded /* raw labels: scratch */, P);
   }
   {
     ProfScope ps(c, "k2k3_normals_labels", 64.0 * P);
-    dim3 grid((W + 255) / 256, H);
-    k2_normals<<<grid, 256, 0, st>>>(out->map[SUMA_MAP_VERTEX], out->map[SUMA_MAP_SEMANTIC], out->map[SUMA_MAP_NORMAL],
-                                     c->eroded, W, H);
-    k3_floodfill<<<grid, 256, 0, st>>>(out->map[SUMA_MAP_VERTEX], c->eroded, out->map[SUMA_MAP_SEMANTIC], W, H);
+    /* raw labels go to the scratch map, the fused kernel writes the refined ones into the frame
+     * (Preprocessing.cpp:327 copies the refined texture over frame.semantic_map) */
+    dim3 grid((W + PRE_TX - 1) / PRE_TX, (H + PRE_TY - 1) / PRE_TY);
+    k23_normals_labels<<<grid, PRE_TX * PRE_TY, 0, st>>>(out->map[SUMA_MAP_VERTEX], c->eroded, out->map[SUMA_MAP_NORMAL],
+                                                       out->map[SUMA_MAP_SEMANTIC], W, H);
   }
   return hipGetLastError();
 }
