@@ -96,7 +96,7 @@ typedef struct suma_params {
    * label_offset/prob_offset reproduce (4,5) or fix (0,0) it; reads past the end yield 0. */
   uint32_t label_offset, prob_offset;
   /* capacity (in surfels) of the HBM arena that holds the parked submap tiles; the reference keeps
-   * them in host RAM (SurfelMap.h:186).  0 = 4 * max_surfels. */
+   * them in host RAM (SurfelMap.h:186).  0 = 16 * max_surfels. */
   uint32_t cache_surfels;
 } suma_params;
 

@@ -286,7 +286,9 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
     CK(hipHostMalloc((void**)&c->h_gn, SUMA_MAX_HYP * sizeof(GnState), hipHostMallocDefault));
     /* submap cache arena */
-    uint64_t cache = params->cache_surfels ? params->cache_surfels : 4ull * params->max_surfels;
+    /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
+     * trajectory stays parked in HBM; re-extracted tiles take fresh arena space */
+    uint64_t cache = params->cache_surfels ? params->cache_surfels : 16ull * params->max_surfels;
     if (cache > 0xffffffffull) cache = 0xffffffffull;
     c->cache_cap = (uint32_t)cache;
     CK(hipMalloc((void**)&c->cache_arena, (size_t)c->cache_cap * sizeof(suma_surfel)));
