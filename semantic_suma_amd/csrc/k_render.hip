@@ -51,6 +51,7 @@ struct RenderArgs {
   /* optional K7 (gen_indexmap.vert:62-81) fused into this pass: the index-map splat of the same
    * surfels from slot[0]'s pose into the data-sized z-buffer */
   int k7_enabled;
+  int k7_same_proj; /* data and model images share one projection: the centre is projected once */
   proj_t k7_q;
   unsigned long long* k7_zbuf;
 };
@@ -193,9 +194,11 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
         surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
         float lp = len3(p);
         if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
+          v3 pp = mk3(0, 0, 0);
+          if (selected || a.k7_same_proj) pp = project01(a.q, p);
           if (k7) {
             /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
-            v3 pr = project01(a.k7_q, p);
+            const v3 pr = a.k7_same_proj ? pp : project01(a.k7_q, p);
             float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
             float zn = 2.0f * pr.z - 1.0f;
             if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
@@ -204,7 +207,6 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
             }
           }
           if (selected) {
-            v3 pp = project01(a.q, p);
             cand = (pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f);
             ppx = pp.x;
           }
@@ -459,6 +461,7 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.slot[0].enabled = a.slot[1].enabled = 0;
   a.k7_enabled = 0;
   a.k7_q = c->pd;
+  a.k7_same_proj = (memcmp(&c->pd, &c->pm, sizeof(proj_t)) == 0) ? 1 : 0;
   a.k7_zbuf = c->zbuf_data;
   return a;
 }
