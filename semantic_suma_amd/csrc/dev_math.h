@@ -132,4 +132,12 @@ SDEV float4 texel(const float4* __restrict__ map, int32_t w, int32_t h, int32_t 
 
 #define SUMA_EMPTY_KEY (~0ull)
 
+/* Depth-tested write into a 64-bit z-buffer (key = depth24 << 32 | id, smaller wins).  A pixel that many
+ * primitives hit (far-range rows of a dense map collect hundreds of surfels) would serialise that many
+ * read-modify-writes on one address; the current value only ever decreases, so a coherent (L2-bypassing)
+ * load first lets every primitive that cannot win skip the atomic altogether.  Same final value. */
+SDEV void zbuf_min(unsigned long long* __restrict__ addr, unsigned long long key) {
+  if (key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(addr, key);
+}
+
 #endif

@@ -106,7 +106,7 @@ __device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, 
   if ((tu * tu + tv * tv) > 1.0f) return; /* render_surfels.frag:22 */
   float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
   if (!(z >= 0.0f && z <= 1.0f)) return; /* near / far clipping */
-  atomicMin(&zbuf[(size_t)j * (size_t)W + (size_t)i], render_key(depth24(z), id, tie));
+  zbuf_min(&zbuf[(size_t)j * (size_t)W + (size_t)i], render_key(depth24(z), id, tie));
 }
 
 /* (inv_pose * surfelPose) * v, render_surfels.vert:44-48 */
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
             float zn = 2.0f * pr.z - 1.0f;
             if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
               unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
-              atomicMin(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
+              zbuf_min(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
             }
           }
           if (selected) {

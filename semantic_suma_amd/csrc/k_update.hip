@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256) k7_indexmap(UpdArgs a) {
     float zn = 2.0f * pr.z - 1.0f;
     if (!(zn >= -1.0f && zn <= 1.0f)) continue;
     unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
-    atomicMin(&a.zbuf[(size_t)(int32_t)fy * a.q.W + (size_t)(int32_t)fx], key);
+    zbuf_min(&a.zbuf[(size_t)(int32_t)fy * a.q.W + (size_t)(int32_t)fx], key);
   }
 }
 
