@@ -805,14 +805,20 @@ struct ExtractArgs {
 };
 
 /* extract_surfels.vert:46-64: stable compaction of the surfels of one submap tile into the
- * cache arena (capacity SUMA_EXTRACT_CAPACITY per tile, SurfelMap.cpp:279) */
+ * cache arena (capacity SUMA_EXTRACT_CAPACITY per tile, SurfelMap.cpp:279).  The selection is sparse
+ * (one 20 m tile out of a 180 m window), so a block takes K12_ITEMS x 1024 surfels per ticket with all
+ * of its loads in flight at once, decides from position + creation stamp only, and re-reads the few
+ * selected records when their output offset is known. */
+#define K12_ITEMS 4u
 __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
-  __shared__ uint32_t s_tile, s_prefix, s_base;
-  __shared__ uint32_t s_wave[TILE_WAVES];
+  __shared__ uint32_t s_tile, s_prefix;
+  __shared__ uint32_t s_cnt[K12_ITEMS][TILE_WAVES];
   const uint32_t S = a.ds->n_surfels;
-  const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
+  const uint32_t span = SUMA_TILE * K12_ITEMS;
+  const uint32_t ntiles = (S + span - 1) / span;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
   const uint32_t base = a.ds->cache_used; /* stable during the kernel: only the finaliser moves it */
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0)
@@ -820,32 +826,69 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
     __syncthreads();
     const uint32_t tile = s_tile;
     if (tile >= ntiles) break;
-    const uint32_t i = tile * SUMA_TILE + threadIdx.x;
-    bool sel = false;
-    Surfel4 s;
-    if (i < S) {
-      s.a = sf[4 * (size_t)i];
-      s.b = sf[4 * (size_t)i + 1];
-      s.c = sf[4 * (size_t)i + 2];
-      s.d = sf[4 * (size_t)i + 3];
-      float Ps[16];
-      load_pose(a.poses, (int32_t)s.c.w, Ps);
-      v3 pos = m4_point(Ps, xyz(s.a));
-      sel = !(sdm_abs(pos.x - a.cx) > a.extent || sdm_abs(pos.y - a.cy) > a.extent);
+    float4 pa[K12_ITEMS];
+    float cnt[K12_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < K12_ITEMS; ++k) { /* all loads first */
+      const uint32_t i = tile * span + k * SUMA_TILE + threadIdx.x;
+      pa[k] = f4(0.f, 0.f, 0.f, 0.f);
+      cnt[k] = 0.f;
+      if (i < S) {
+        pa[k] = sf[4 * (size_t)i];
+        cnt[k] = sf[4 * (size_t)i + 2].w;
+      }
     }
-    BlockRank br = block_rank(sel, s_wave);
+    bool sel[K12_ITEMS];
+    uint32_t below[K12_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < K12_ITEMS; ++k) {
+      const uint32_t i = tile * span + k * SUMA_TILE + threadIdx.x;
+      sel[k] = false;
+      if (i < S) {
+        float Ps[16];
+        load_pose(a.poses, (int32_t)cnt[k], Ps);
+        v3 pos = m4_point(Ps, xyz(pa[k]));
+        sel[k] = !(sdm_abs(pos.x - a.cx) > a.extent || sdm_abs(pos.y - a.cy) > a.extent);
+      }
+      const unsigned long long b = __ballot(sel[k]);
+      below[k] = __popcll(b & ((1ull << lane) - 1ull));
+      if (lane == 0) s_cnt[k][wave] = __popcll(b);
+    }
+    __syncthreads();
+    uint32_t total = 0, rank[K12_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < K12_ITEMS; ++k) { /* item order = (k, wave, lane) = input order */
+      uint32_t off = total;
+#pragma unroll
+      for (int w = 0; w < (int)TILE_WAVES; ++w) {
+        const uint32_t c = s_cnt[k][w];
+        if (w < wave) off += c;
+        total += c;
+      }
+      rank[k] = off + below[k];
+    }
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, total, a.epoch, threadIdx.x);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();
-    if (sel) {
-      uint32_t k = s_prefix + br.rank;
-      if (k < SUMA_EXTRACT_CAPACITY && (uint64_t)base + k < a.arena_cap) store_surfel(a.arena, base + k, s);
+#pragma unroll
+    for (uint32_t k = 0; k < K12_ITEMS; ++k) {
+      if (sel[k]) {
+        const uint32_t i = tile * span + k * SUMA_TILE + threadIdx.x;
+        const uint32_t dst = s_prefix + rank[k];
+        if (dst < SUMA_EXTRACT_CAPACITY && (uint64_t)base + dst < a.arena_cap) {
+          Surfel4 s;
+          s.a = pa[k];
+          s.b = sf[4 * (size_t)i + 1];
+          s.c = sf[4 * (size_t)i + 2];
+          s.d = sf[4 * (size_t)i + 3];
+          store_surfel(a.arena, base + dst, s);
+        }
+      }
     }
-    if (tile == ntiles - 1 && threadIdx.x == 0) a.ds->n_extracted = s_prefix + br.total;
+    if (tile == ntiles - 1 && threadIdx.x == 0) a.ds->n_extracted = s_prefix + total;
   }
-  (void)s_base;
   if (is_finaliser(s_tile, ntiles)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
     if (threadIdx.x == 0) {
@@ -884,7 +927,7 @@ hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float 
   a.cy = cy;
   a.extent = extent;
   ProfScope ps(c, "k12_extract_submap", 64.0 * (double)c->known_surfels);
-  k12_extract<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), SUMA_TILE, 0, c->stream>>>(a);
+  k12_extract<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + K12_ITEMS - 1) / K12_ITEMS), SUMA_TILE, 0, c->stream>>>(a);
   return hipGetLastError();
 }
 
