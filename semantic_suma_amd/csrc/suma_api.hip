@@ -966,7 +966,11 @@ static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_fram
   if (r) return r;
   CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-  CK(hipStreamSynchronize(c->stream));
+  for (;;) { /* poll instead of a blocking wait */
+    hipError_t q = hipStreamQuery(c->stream);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) CK(q);
+  }
   resolve_stats(s, false); /* everything enqueued before this point has completed */
   c->known_surfels = c->h_ds->n_surfels;
   memcpy(T, c->h_gn[0].Tk, 16 * sizeof(double));
