@@ -364,3 +364,37 @@ def test_capacity_overflow_is_reported(hip):
     hp.processScan(pts, lab, prob)
     with pytest.raises(hip.SumaError, match="capacity"):
         hp.map.size()
+
+
+def test_pipeline_model_image_differs_from_data_image(hip, oracle_lib):
+    """model_width/height/fov != data_*: separate projections for K4 (model image) and K7 / K9 (data image),
+    bilinear taps of K6 across differently sized maps"""
+    from semantic_suma_amd.types import default_params
+    p = default_params(data_width=900, data_height=64, model_width=1024, model_height=48, model_fov_up=2.0,
+                       model_fov_down=-24.0, model_max_depth=70.0)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for k in range(4):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=8)
+        op.process_scan(pts, lab, prob, fixed_iterations=8)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k} pose"
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"scan {k} stats"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        frames_equal(hp.frame(2), op.frame(2), f"scan {k} model frame")
+
+
+def test_tiny_and_odd_image_sizes(hip, oracle_lib):
+    """16 beams x 180 columns and a width that is not a multiple of any tile size"""
+    for (w, h) in ((180, 16), (1000, 40)):
+        p = params_with_size(w, h)
+        hp = hip.SurfelMapping(p)
+        op = oracle_lib.OraclePipeline(p)
+        for k in range(3):
+            pts, lab, prob, _ = get_scan(k, w, True, h)
+            hp.processScan(pts, lab, prob, fixed_iterations=6)
+            op.process_scan(pts, lab, prob, fixed_iterations=6)
+            assert np.array_equal(hp.getCurrentPose(), op.pose()), f"{w}x{h} scan {k} pose"
+            assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"{w}x{h} scan {k} surfels"
+            for f in (0, 2):
+                frames_equal(hp.frame(f), op.frame(f), f"{w}x{h} scan {k} frame {f}")
