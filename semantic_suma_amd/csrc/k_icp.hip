@@ -251,6 +251,12 @@ struct IterArgs {
   int init;
   uint32_t iteration0;
   PoseD T0;
+  /* closing launch of the pipeline's minimisation: also emit the sensor pose the re-rendering
+   * (SurfelMapping.cpp:406) uses, pose_base * increment as float + its rigid inverse, so that the
+   * render pass can be enqueued without waiting for the host to read the increment back */
+  int emit_pose;
+  PoseD pose_base;
+  float* pose_block; /* 16 floats pose, 16 floats inverse */
 };
 
 /* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
@@ -439,7 +445,20 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   }
 
   if (!PIXEL || (done && !g.eval_only) || (g.eval_only && pending)) {
-    if (writer) gout->pending = 0;
+    if (writer) {
+      gout->pending = 0;
+      if (!PIXEL && g.emit_pose && blockIdx.y == 0) {
+        double Pd[16];
+        mul4d(g.pose_base.m, Tk, Pd); /* currentPose_new_ * increment, in double as on the host */
+        float Pf[16], Pinv[16];
+        for (int i = 0; i < 16; ++i) Pf[i] = (float)Pd[i];
+        rigid_inverse_dev(Pf, Pinv);
+        for (int i = 0; i < 16; ++i) {
+          g.pose_block[i] = Pf[i];
+          g.pose_block[16 + i] = Pinv[i];
+        }
+      }
+    }
     return;
   }
 
@@ -626,6 +645,9 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.pixel = pixel;
   g.history = with_history ? c->gn_history : nullptr;
   g.history_cap = c->gn_history_cap;
+  g.emit_pose = (!pixel && c->gn_emit_pose) ? 1 : 0;
+  for (int i = 0; i < 16; ++i) g.pose_base.m[i] = c->gn_pose_base[i];
+  g.pose_block = c->pose_block;
   g.init = c->gn_init_pending;
   g.iteration0 = c->gn_iteration0;
   for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];

@@ -50,6 +50,7 @@ struct RenderArgs {
   RenderSlot slot[2];
   /* optional K7 (gen_indexmap.vert:62-81) fused into this pass: the index-map splat of the same
    * surfels from slot[0]'s pose into the data-sized z-buffer */
+  const float* inv_pose_dev; /* if set: slot 0 (and the fused K7) take the inverse pose from HBM */
   int k7_enabled;
   int k7_same_proj; /* data and model images share one projection: the centre is projected once */
   proj_t k7_q;
@@ -184,6 +185,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
     for (int sl = 0; sl < 2; ++sl) {
       const RenderSlot& slot = a.slot[sl];
       if (!slot.enabled) continue; /* kernel-uniform */
+      const float* inv_pose = (sl == 0 && a.inv_pose_dev != nullptr) ? a.inv_pose_dev : slot.inv_pose.m;
       /* ---- phase 1a ---- */
       const bool selected = live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr));
       const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
@@ -191,7 +193,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
       v3 p = mk3(0, 0, 0), n = p;
       float ppx = 0.f;
       if (selected || k7) {
-        surfel_to_sensor(a.poses, slot.inv_pose.m, count, xyz(s0), xyz(s1), &p, &n);
+        surfel_to_sensor(a.poses, inv_pose, count, xyz(s0), xyz(s1), &p, &n);
         float lp = len3(p);
         if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
           v3 pp = mk3(0, 0, 0);
@@ -398,6 +400,7 @@ struct ResolveArgs {
    * semantic copied from sa_src (the semantic map is not re-rendered by render_active) */
   float4 *vm, *nm, *sm;
   const float4* sm_src;
+  const float* inv_dev; /* if set: inverse pose from HBM instead of inv_a / inv_b */
 };
 
 /* single z-buffer -> up to three maps */
@@ -406,7 +409,9 @@ __global__ void __launch_bounds__(256) k_resolve(ResolveArgs a) {
   if (pix >= a.Pm) return;
   unsigned long long key = a.zbuf_a[pix];
   a.zbuf_a[pix] = SUMA_EMPTY_KEY;
-  ResolveOut o = resolve_pixel(key, a.tie, a.surfels, a.poses, a.inv_a.m, a.inv_b.m);
+  const float* ia = a.inv_dev ? a.inv_dev : a.inv_a.m;
+  const float* ib = a.inv_dev ? a.inv_dev : a.inv_b.m;
+  ResolveOut o = resolve_pixel(key, a.tie, a.surfels, a.poses, ia, ib);
   if (a.va) a.va[pix] = o.v;
   if (a.na) a.na[pix] = o.n;
   if (a.sa) a.sa[pix] = o.s;
@@ -459,6 +464,7 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.use_stability = c->p.use_stability;
   a.thr = thr;
   a.slot[0].enabled = a.slot[1].enabled = 0;
+  a.inv_pose_dev = nullptr;
   a.k7_enabled = 0;
   a.k7_q = c->pd;
   a.k7_same_proj = (memcmp(&c->pd, &c->pm, sizeof(proj_t)) == 0) ? 1 : 0;
@@ -566,10 +572,12 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
  * refreshed by these calls; restated as such. */
 hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_threshold, int active, int fuse_k7,
                                     suma_frame* mirror) {
-  float inv[16];
-  rigid_inverse_f(pose, inv);
+  /* pose == NULL: the pose block written by the closing Gauss-Newton launch (HBM) is used */
+  float inv[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+  if (pose) rigid_inverse_f(pose, inv);
   int32_t thr = (int32_t)(c->timestamp - 100u);
   RenderArgs a = render_args(c, conf_threshold, thr);
+  if (!pose) a.inv_pose_dev = c->pose_block + 16;
   a.slot[0].enabled = 1;
   a.slot[0].mode = active ? 1 : 0;
   a.slot[0].tie = TIE_LOW_INDEX;
@@ -584,6 +592,7 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   set_m4(r.inv_a, inv);
   set_m4(r.inv_b, inv);
   r.tie = TIE_LOW_INDEX;
+  if (!pose) r.inv_dev = c->pose_block + 16;
   suma_frame* tgt = active ? c->new_frame : c->old_frame;
   r.va = tgt->map[0];
   r.na = tgt->map[1];

@@ -128,24 +128,6 @@ __device__ __forceinline__ void finalise_tickets(DevState* ds, unsigned long lon
   if (threadIdx.x == 0) ds->ticket = 0;
 }
 
-/* inverse of a rigid transform evaluated in double from the fp32 matrix, rounded once:
- * R^T, -R^T t (the reference uses a general inverse, update_surfels.vert:197; equal to fp32
- * rounding on rigid poses) */
-__device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
-  double R[9], t[3];
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) R[3 * c + r] = (double)m[4 * c + r];
-  for (int r = 0; r < 3; ++r) t[r] = (double)m[12 + r];
-  for (int c = 0; c < 3; ++c)
-    for (int r = 0; r < 3; ++r) out[4 * c + r] = (float)R[3 * r + c];
-  for (int r = 0; r < 3; ++r) {
-    double s = (R[3 * r + 0] * t[0] + R[3 * r + 1] * t[1]) + R[3 * r + 2] * t[2];
-    out[12 + r] = (float)(-s);
-  }
-  out[3] = out[7] = out[11] = 0.0f;
-  out[15] = 1.0f;
-}
-
 /* ---------------------------------------------------------------------------------------------
  * K8 + clear of the integration mask
  * ------------------------------------------------------------------------------------------- */

@@ -285,6 +285,9 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->gn_history, (size_t)c->gn_history_cap * 16 * sizeof(double)));
     CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
     CK(hipHostMalloc((void**)&c->h_gn, SUMA_MAX_HYP * sizeof(GnState), hipHostMallocDefault));
+    CK(hipMalloc((void**)&c->pose_block, 32 * sizeof(float)));
+    CK(hipEventCreateWithFlags(&c->ev_result, hipEventDisableTiming));
+    c->gn_emit_pose = 0;
     /* submap cache arena */
     /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
      * trajectory stays parked in HBM; re-extracted tiles take fresh arena space */
@@ -325,7 +328,8 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.b);
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
-  void* dev[] = {c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
+  if (c->ev_result) hipEventDestroy(c->ev_result);
+  void* dev[] = {c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
                  c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs};
@@ -876,12 +880,13 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
       return r;
     }
   }
-  if (hipHostMalloc((void**)&s->h_stats, sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->h_stats, 2 * sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
     g_create_error = "hipHostMalloc failed";
     suma_pipeline_destroy(s);
     return SUMA_ERR_HIP;
   }
   s->stats_pending = false;
+  s->stats_slot = 0;
   eye_d(s->current_pose);
   eye_d(s->last_pose);
   eye_d(s->pose_old);
@@ -931,7 +936,7 @@ static void resolve_stats(suma_pipeline* s, bool need_sync) {
   if (!s->stats_pending) return;
   if (need_sync) hipStreamSynchronize(s->c->stream);
   suma_icp_stats st;
-  fill_stats(*s->h_stats, &st);
+  fill_stats(s->h_stats[s->stats_slot], &st);
   st.iterations = s->stats_mst.iterations;
   st.converged = s->stats_mst.converged;
   s->stats = st;
@@ -978,7 +983,12 @@ static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_fram
   return check_overflow(c);
 }
 
-/* SurfelMapping::updatePose, SurfelMapping.cpp:372-476 */
+/* SurfelMapping::updatePose, SurfelMapping.cpp:372-476.
+ * Everything up to and including the statistics pass depends only on the FIRST minimisation (the
+ * reference re-renders and takes its statistics before it looks at the fallback condition,
+ * :406-423 vs :434-449), so it is enqueued in one go: the closing Gauss-Newton launch leaves the
+ * re-render pose in HBM, and the host reads the increment back while the GPU is already busy with
+ * the re-render and the statistics pass -- the stream never drains inside a scan. */
 static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   suma_ctx* c = s->c;
   double T0[16], increment[16];
@@ -987,40 +997,72 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   else
     eye_d(T0);
   suma_icp_stats mst;
-  int r = minimize_cfg(s, s->current_frame, c->new_frame, T0, increment, fixed_iterations, &mst);
-  if (r) return r;
-
-  double inv_last[16], delta[16], posed[16], I[16];
-  float posef[16];
-  rigid_inv_d(s->last_increment, inv_last);
-  mul4_d(inv_last, increment, delta);
-  mul4_d(s->pose_new, increment, posed);
-  cast_f(posed, posef);
-  c->rendered.valid = false; /* NEW is re-rendered from the ICP pose */
-  /* updateMap() will build the index map (K7) from this very pose unless the fallback ICP changes
-   * it: fuse the splat into this pass over the surfels */
-  /* ... and lastModelFrame_->copy(newMapFrame) (:407) is written by the same resolve pass */
-  CK(launch_map_render_single(c, posef, conf_threshold(s), 1, 1, s->last_model)); /* :406-407 */
-  c->k7.valid = true;
-  c->k7.map_version = c->map_version;
-  c->k7.params_version = c->params_version;
-  memcpy(c->k7.pose, posef, sizeof(posef));
+  /* --- frame-to-model minimisation (:384-396), result copied to the host, event recorded --- */
+  {
+    suma_params saved = c->p;
+    if (fixed_iterations > 0) {
+      c->p.max_iterations = (uint32_t)fixed_iterations;
+      c->p.stopping_threshold = 0.0f;
+      c->p.delta = 0.0f;
+    }
+    c->icp_current = s->current_frame;
+    c->icp_model = c->new_frame;
+    c->gn_emit_pose = 1;
+    memcpy(c->gn_pose_base, s->pose_new, sizeof(c->gn_pose_base));
+    int r0 = enqueue_minimize(c, T0, 1, 0);
+    c->gn_emit_pose = 0;
+    c->p = saved;
+    if (r0) return r0;
+    CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+    CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
+    CK(hipEventRecord(c->ev_result, c->stream));
+  }
+  /* --- re-render from pose_new * increment (pose taken from HBM), K7 splat and the
+   *     lastModelFrame copy fused in (:406-407) --- */
+  c->rendered.valid = false;
+  CK(launch_map_render_single(c, nullptr, conf_threshold(s), 1, 1, s->last_model));
+  /* --- statistics pass (:411-423) --- */
+  double I[16];
   eye_d(I);
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;
   CK(launch_gn_init(c, I, 1, 0, 0));
   {
     ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
-    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1)); /* :411-413, statistics only */
+    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
   }
   {
     ProfScope ps(c, "k6_icp_finish", 0.0);
     CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
   }
-  resolve_stats(s, true); /* (no-op unless the previous scan's statistics were never looked at) */
-  CK(hipMemcpyAsync(s->h_stats, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  const uint32_t slot = s->stats_slot ^ 1u; /* the previous scan's copy may not have been looked at yet */
+  CK(hipMemcpyAsync(&s->h_stats[slot], gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  /* --- wait for the minimisation result only (poll: no blocking wake-up) --- */
+  for (;;) {
+    hipError_t q = hipEventQuery(c->ev_result);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) CK(q);
+  }
+  resolve_stats(s, false); /* the previous scan's statistics copy precedes ev_result in the stream */
+  s->stats_slot = slot;
+  c->known_surfels = c->h_ds->n_surfels;
+  memcpy(increment, c->h_gn[0].Tk, sizeof(increment));
+  fill_stats(c->h_gn[0], &mst);
+  int r = check_overflow(c);
+  if (r) return r;
   s->stats_mst = mst;
   s->stats_pending = true;
+
+  double inv_last[16], delta[16], posed[16];
+  float posef[16];
+  rigid_inv_d(s->last_increment, inv_last);
+  mul4_d(inv_last, increment, delta);
+  mul4_d(s->pose_new, increment, posed);
+  cast_f(posed, posef); /* the same value the closing launch wrote to HBM */
+  c->k7.valid = true;
+  c->k7.map_version = c->map_version;
+  c->k7.params_version = c->params_version;
+  memcpy(c->k7.pose, posef, sizeof(posef));
 
   float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
   float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));

@@ -99,6 +99,10 @@ struct suma_ctx {
   GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
   int64_t* gn_partial; /* 2 x SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
   uint32_t gn_launch;  /* launches since the last gn_init */
+  int gn_emit_pose;        /* the closing launch of the chain being enqueued writes pose_block */
+  double gn_pose_base[16];
+  float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
+  hipEvent_t ev_result;    /* recorded after the minimisation result has been copied to the host */
   int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
   uint32_t gn_iteration0;
   double gn_T0_host[16];
@@ -174,8 +178,9 @@ struct suma_pipeline {
   uint32_t track_loss;
   /* the statistics pass of updatePose (SurfelMapping.cpp:411-423) is read back lazily: its copy is
    * enqueued, and resolved at the next synchronisation point instead of stalling the scan */
-  GnState* h_stats; /* pinned */
+  GnState* h_stats; /* pinned, 2 entries: the copy of scan t may still be in flight when scan t+1 enqueues its own */
   bool stats_pending;
+  uint32_t stats_slot;
   suma_icp_stats stats_mst;
 };
 
