@@ -223,16 +223,6 @@ __global__ void k_gn_init(GnState* gn, const double* T0s, double* history, uint3
   }
   gn_reset(g, t, iteration0);
 }
-/* single hypothesis, T0 by value (no staging copy on the per-scan path) */
-__global__ void k_gn_init1(GnState* g, PoseD T0, double* history, uint32_t iteration0) {
-  int t = threadIdx.x;
-  if (t < 16) {
-    g->Tk[t] = T0.m[t];
-    if (history != nullptr) history[t] = T0.m[t];
-  }
-  gn_reset(g, t, iteration0);
-}
-
 struct IterArgs {
   IcpArgs a;
   const GnState* gin;  /* state written by the previous launch */

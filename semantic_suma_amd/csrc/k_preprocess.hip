@@ -66,13 +66,6 @@ __global__ void __launch_bounds__(256)
   semantic[pix] = f4(l, l, l, prob);
 }
 
-__device__ __forceinline__ int32_t wrapx(int32_t x, int32_t w) {
-  /* gen_normalmap.frag:24-32 wrap() for |offset| < w */
-  if (x >= w) x -= w;
-  if (x < 0) x += w;
-  return x;
-}
-
 /* K2 + K3 fused over LDS tiles.  A block owns a PRE_TX x PRE_TY patch of the image and stages the
  * vertex and semantic maps of the patch plus a halo of 3 texels (x wraps around the 360-degree
  * image, rows outside the image are the zero border) in LDS: the 5-point normal / erosion stencil

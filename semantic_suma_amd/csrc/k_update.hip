@@ -713,15 +713,6 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
 /* ---------------------------------------------------------------------------------------------
  * pose table (SurfelMap.cpp:494-495, 485-490): poses and their rigid inverses
  * ------------------------------------------------------------------------------------------- */
-__global__ void k_set_pose1(float* poses, float* poses_inv, uint32_t idx, m4 pose) {
-  if (threadIdx.x != 0) return;
-  float inv[16];
-  rigid_inverse_dev(pose.m, inv);
-  for (int i = 0; i < 16; ++i) {
-    poses[16 * (size_t)idx + i] = pose.m[i];
-    poses_inv[16 * (size_t)idx + i] = inv[i];
-  }
-}
 __global__ void k_set_poses(float* poses, float* poses_inv, const float* src, uint32_t first, uint32_t n) {
   uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
@@ -753,12 +744,6 @@ hipError_t launch_clear_index_zbuf(suma_ctx* c) {
   return hipGetLastError();
 }
 
-hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16) {
-  m4 p;
-  set_m4(p, pose16);
-  k_set_pose1<<<1, 64, 0, c->stream>>>(c->poses, c->poses_inv, idx, p);
-  return hipGetLastError();
-}
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n) {
   if (n == 0) return hipSuccess;
   k_set_poses<<<(n + 255) / 256, 256, 0, c->stream>>>(c->poses, c->poses_inv, d_src, first, n);

@@ -18,7 +18,7 @@
 
 #define SUMA_TILE 1024u       /* items per compaction tile = threads per block (16 waves) */
 #define SUMA_COMPACT_BLOCKS 512u /* grid of the ticketed compaction kernels: 2 blocks per CU */
-#define SUMA_STREAM_BLOCKS 2048u /* grid of the grid-stride / ticket kernels: 8 blocks per CU */
+#define SUMA_STREAM_BLOCKS 2048u /* grid cap of the grid-stride surfel kernels: 8 blocks of 256 per CU */
 #define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
 #define SUMA_MAX_HYP 64u
 
@@ -32,7 +32,7 @@ struct DevState {
   uint32_t n_extracted;    /* K12: surfels written by the last extraction */
   uint32_t overflow;       /* bit 0: surfel capacity, bit 1: cache arena, bit 2: extract capacity */
   uint32_t ticket;         /* dynamic tile id of the look-back compaction kernels */
-  uint32_t done_blocks;    /* blocks that left the current compaction kernel */
+  uint32_t reserved0;
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
   uint32_t pad[6];
 };
@@ -89,7 +89,7 @@ struct suma_ctx {
 
   /* preprocessing scratch */
   unsigned long long* zbuf_data; /* P keys: K1 and K7 */
-  float4* eroded;                /* P */
+  float4* eroded;                /* P: raw labels of K1 (scratch between k1_resolve and the fused K2/K3) */
   float4* scan_points;           /* staging for host scans */
   float *scan_labels, *scan_probs;
   uint32_t scan_cap;
@@ -226,7 +226,6 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
                              float cy, float extent, int k7_done);
 hipError_t launch_clear_index_zbuf(suma_ctx* c);
-hipError_t launch_set_pose(suma_ctx* c, uint32_t idx, const float* pose16);
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);
 hipError_t launch_fill_identity_poses(suma_ctx* c);
 hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent);
