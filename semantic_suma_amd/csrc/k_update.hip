@@ -56,37 +56,45 @@ __device__ __forceinline__ void lookback_publish(unsigned long long* __restrict_
   __hip_atomic_fetch_add(&group[tile >> 6], (1ull << 32) | (unsigned long long)agg, __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
 }
-/* called by one full wave; returns the number of selected items in all tiles before `tile` */
+/* called by one full wave; returns the number of selected items in all tiles before `tile`.
+ * Every spin is bounded (SUMA_SPIN_LIMIT polls, seconds of wall time): a protocol error must surface
+ * as an error code (DevState.overflow bit 3), never as a hung GPU. */
+#define SUMA_SPIN_LIMIT (1u << 26)
 __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
-                                     uint32_t tile, uint32_t epoch, int lane) {
+                                     uint32_t tile, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
   const uint32_t g = tile >> 6;
   uint32_t sum = 0;
+  bool timed_out = false;
   /* complete groups before mine: every group before g holds exactly 64 tiles */
   for (uint32_t gi = lane; gi < g; gi += 64) {
     unsigned long long w;
+    uint32_t spins = 0;
     do {
       w = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((uint32_t)(w >> 32) != 64u);
+    } while ((uint32_t)(w >> 32) != 64u && ++spins < SUMA_SPIN_LIMIT);
+    timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
   }
   /* earlier tiles of my own group */
   const uint32_t j = tile & 63u;
   if ((uint32_t)lane < j) {
     unsigned long long w;
+    uint32_t spins = 0;
     do {
       w = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0);
+    } while (((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0) && ++spins < SUMA_SPIN_LIMIT);
+    timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
   }
+  if (timed_out) atomicOr(fault, 8u);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
   return sum;
 }
 __device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
-                                    uint32_t tile, uint32_t ntiles, uint32_t agg, uint32_t epoch, int lane) {
-  (void)ntiles;
+                                    uint32_t tile, uint32_t agg, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
   if (lane == 0) lookback_publish(status, group, tile, agg, epoch);
-  return lookback_collect(status, group, tile, epoch, lane);
+  return lookback_collect(status, group, tile, epoch, lane, fault);
 }
 
 /* block-level stable ranking of a flag: returns the rank of this thread among the block's
@@ -488,7 +496,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k9_update(UpdArgs a) {
       const uint32_t tile = pair * K9_PAIR + h;
       if (tile >= ntiles) break;
       if (threadIdx.x < 64) {
-        uint32_t pre = lookback_collect(a.status, a.group, tile, a.epoch, threadIdx.x);
+        uint32_t pre = lookback_collect(a.status, a.group, tile, a.epoch, threadIdx.x, &a.ds->overflow);
         if (threadIdx.x == 0) s_prefix = pre;
       }
       __syncthreads();
@@ -592,7 +600,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     if (threadIdx.x == 0)
       for (int w = 0; w < (int)TILE_WAVES; ++w) new_count += s_wave_b[w];
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, br.total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, br.total, a.epoch, threadIdx.x, &a.ds->overflow);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();
@@ -835,7 +843,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
       rank[k] = off + below[k];
     }
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, a.group, tile, ntiles, total, a.epoch, threadIdx.x);
+      uint32_t pre = lookback_prefix(a.status, a.group, tile, total, a.epoch, threadIdx.x, &a.ds->overflow);
       if (threadIdx.x == 0) s_prefix = pre;
     }
     __syncthreads();

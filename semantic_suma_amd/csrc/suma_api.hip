@@ -749,6 +749,7 @@ extern "C" int suma_map_update_poses(suma_ctx* c, const float* poses16, uint32_t
 static int check_overflow(suma_ctx* c) {
   if (c->h_ds->overflow & 1u) return fail(c, SUMA_ERR_CAPACITY, "surfel capacity (max_surfels) exceeded; map truncated");
   if (c->h_ds->overflow & 2u) return fail(c, SUMA_ERR_CAPACITY, "submap cache arena (cache_surfels) exhausted");
+  if (c->h_ds->overflow & 8u) return fail(c, SUMA_ERR_HIP, "stable-compaction hand-off timed out (internal error)");
   return SUMA_OK;
 }
 

@@ -30,7 +30,7 @@ struct DevState {
   uint32_t n_data;         /* D: new surfels emitted by K10 (before the K11 area filter) */
   uint32_t n_kept_data;
   uint32_t n_extracted;    /* K12: surfels written by the last extraction */
-  uint32_t overflow;       /* bit 0: surfel capacity, bit 1: cache arena, bit 2: extract capacity */
+  uint32_t overflow;       /* bit 0: surfel capacity, bit 1: cache arena, bit 2: extract capacity, bit 3: compaction spin limit */
   uint32_t ticket;         /* dynamic tile id of the look-back compaction kernels */
   uint32_t reserved0;
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
