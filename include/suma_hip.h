@@ -136,6 +136,28 @@ uint32_t suma_pipeline_timestamp(const suma_pipeline* s);
 /* which: 0 current data frame, 1 last model frame, 2 current model frame */
 suma_frame* suma_pipeline_frame(suma_pipeline* s, int which);
 
+/* ---- loop-closure verification, the device side of SurfelMapping::checkLoopClosure
+ *      (SurfelMapping.cpp:662-757): render the inactive map from a candidate pose, run the
+ *      frame-to-model minimisation from each initial guess, and -- for guesses that pass the
+ *      valid / outlier gates -- render the composed (old + new) view and evaluate the objective at
+ *      identity against it.  Faithful to the reference's sequencing, including its quirk that after
+ *      a passing guess the objective keeps pointing at the composed frame for the remaining guesses
+ *      (setData is called once before the loop, :693, and again inside the branch, :719).
+ *      The candidate search, thresholds on the returned ratios and the pose-graph edges stay with the
+ *      caller (SurfelMapping / gtsam are out of scope). */
+typedef struct suma_loop_result {
+  double gn_pose[16];            /* LieGaussNewton::pose() of this guess (relative to pose_prior) */
+  suma_icp_stats after_minimize; /* jacobianProducts at that pose (:705): valid / outlier ratios */
+  int32_t passed;                /* valid_ratio > min_valid_ratio && outlier_ratio < max_outlier_ratio (:713) */
+  float pose_old[16];            /* (pose_prior * gn_pose).cast<float>() (:714) */
+  suma_icp_stats composed;       /* jacobianProducts at identity against composedFrame (:723); zero if !passed */
+  double JtJ[36];                /* information matrix of that evaluation (result_old_.information, :744) */
+} suma_loop_result;
+int suma_loop_closure_verify(suma_ctx* ctx, const suma_frame* current, const double pose_prior[16],
+                             const double* initializations, uint32_t n_init, const float pose_new[16],
+                             float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
+                             suma_loop_result* out);
+
 /* ---- device scratch for callers that keep scans resident in HBM (bench, replay) */
 int suma_device_alloc(suma_ctx* ctx, uint64_t bytes, void** d_ptr);
 int suma_device_free(suma_ctx* ctx, void* d_ptr);

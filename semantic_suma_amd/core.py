@@ -35,6 +35,12 @@ class SumaError(RuntimeError):
     """Raised for every negative return code of the C-ABI (the reference throws std::runtime_error)."""
 
 
+class LoopResult(C.Structure):
+    """suma_loop_result (include/suma_hip.h)"""
+    _fields_ = [("gn_pose", C.c_double * 16), ("after_minimize", IcpStats), ("passed", C.c_int32),
+                ("pose_old", C.c_float * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("bytes", C.c_double)]
 
@@ -95,6 +101,7 @@ def lib():
     L.suma_map_download_radius_conf.argtypes = [vp, vp]
     L.suma_map_download_integrated.argtypes = [vp, vp]
     L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
+    L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
     L.suma_pipeline_destroy.argtypes = [vp]
     L.suma_pipeline_destroy.restype = None
@@ -453,6 +460,25 @@ class SurfelMap:
         ij = np.zeros(2, dtype=np.int32)
         self.ctx.check(self.ctx.L.suma_map_counts(self.ctx.h, C.byref(a), C.byref(b), C.byref(cc), _ptr(ij)))
         return a.value, b.value, cc.value, (int(ij[0]), int(ij[1]))
+
+
+def loop_closure_verify(ctx: Context, current: Frame, pose_prior, initializations, pose_new, conf_threshold: float,
+                        min_valid_ratio: float = 0.2, max_outlier_ratio: float = 0.85):
+    """device side of SurfelMapping::checkLoopClosure (SurfelMapping.cpp:662-757); returns one dict per guess"""
+    prior = _cm(pose_prior, np.float64)
+    inits = np.ascontiguousarray(np.asarray(initializations, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
+    pn = _cm(pose_new, np.float32)
+    n = inits.shape[0]
+    res = (LoopResult * n)()
+    ctx.check(ctx.L.suma_loop_closure_verify(ctx.h, current.h, _ptr(prior), _ptr(inits), n, _ptr(pn), conf_threshold,
+                                             min_valid_ratio, max_outlier_ratio, res), "suma_loop_closure_verify")
+    out = []
+    for k in range(n):
+        r = res[k]
+        out.append(dict(gn_pose=np.array(r.gn_pose[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
+                        passed=bool(r.passed), pose_old=np.array(r.pose_old[:], dtype=np.float32).reshape(4, 4).T.copy(),
+                        composed=r.composed.as_dict(), JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy()))
+    return out
 
 
 class SurfelMapping:

@@ -833,6 +833,61 @@ extern "C" int suma_map_counts(suma_ctx* c, uint32_t* n_updated, uint32_t* n_new
 }
 
 /* ---------------------------------------------------------------------------------------------
+ * loop-closure verification (SurfelMapping.cpp:662-757)
+ * ------------------------------------------------------------------------------------------- */
+static void mul4_dd(const double* A, const double* B, double* C) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r)
+      C[4 * c + r] =
+          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+}
+
+extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, const double pose_prior[16],
+                                        const double* initializations, uint32_t n_init, const float pose_new[16],
+                                        float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
+                                        suma_loop_result* out) {
+  if (!c || !current || !pose_prior || !initializations || !pose_new || !out) return SUMA_ERR_INVALID;
+  float prior_f[16];
+  for (int i = 0; i < 16; ++i) prior_f[i] = (float)pose_prior[i];
+  int r = suma_map_render_inactive(c, prior_f, conf_threshold); /* :679 */
+  if (r) return r;
+  r = suma_icp_set_data(c, current, c->old_frame); /* :693 */
+  if (r) return r;
+  for (uint32_t k = 0; k < n_init; ++k) {
+    suma_loop_result* o = &out[k];
+    memset(o, 0, sizeof(*o));
+    suma_icp_stats mst;
+    r = suma_icp_minimize(c, initializations + 16 * (size_t)k, o->gn_pose, nullptr, 0, nullptr, &mst); /* :700 */
+    if (r) return r;
+    /* objective_->jacobianProducts(JtJ, Jtr) at the pose the minimisation left (:705); Frame2Model's
+     * iteration counter keeps running, which only matters for the Tukey weight */
+    const uint32_t iteration = mst.iterations + (mst.converged ? 1u : 0u);
+    r = suma_icp_jacobian_products(c, o->gn_pose, iteration, nullptr, nullptr, nullptr, &o->after_minimize);
+    if (r) return r;
+    o->after_minimize.iterations = mst.iterations;
+    o->after_minimize.converged = mst.converged;
+    const suma_icp_stats& s0 = o->after_minimize;
+    const float valid_ratio = (float)s0.valid / (float)(s0.valid + s0.invalid);
+    const float outlier_ratio = (float)s0.outlier / (float)(s0.outlier + s0.inlier);
+    double pd[16];
+    mul4_dd(pose_prior, o->gn_pose, pd);
+    for (int i = 0; i < 16; ++i) o->pose_old[i] = (float)pd[i];
+    o->passed = (valid_ratio > min_valid_ratio && outlier_ratio < max_outlier_ratio) ? 1 : 0; /* :713 */
+    if (o->passed) {
+      r = suma_map_render_composed(c, o->pose_old, pose_new, conf_threshold); /* :717 */
+      if (r) return r;
+      r = suma_icp_set_data(c, current, c->composed_frame); /* :719 -- stays set for the next guess */
+      if (r) return r;
+      double I[16];
+      for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.0 : 0.0;
+      r = suma_icp_jacobian_products(c, I, 0, o->JtJ, nullptr, nullptr, &o->composed); /* :720-723 */
+      if (r) return r;
+    }
+  }
+  return SUMA_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
  * SurfelMapping::processScan
  * ------------------------------------------------------------------------------------------- */
 static void resolve_stats(suma_pipeline* s, bool need_sync);

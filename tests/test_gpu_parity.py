@@ -398,3 +398,56 @@ def test_tiny_and_odd_image_sizes(hip, oracle_lib):
             assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"{w}x{h} scan {k} surfels"
             for f in (0, 2):
                 frames_equal(hp.frame(f), op.frame(f), f"{w}x{h} scan {k} frame {f}")
+
+
+def test_loop_closure_verification(hip, oracle_lib):
+    """device side of SurfelMapping::checkLoopClosure (SurfelMapping.cpp:662-757) against the same sequence
+    of oracle primitives: render_inactive -> 3 x (minimize, jacobianProducts, [render_composed, jacobianProducts])"""
+    p = params_with_size(900, max_iterations=8)
+    ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 4)
+    # age the map: everything becomes "inactive" (creation stamp < timestamp - 100)
+    surf = hmap.getAllSurfels()
+    hmap.upload(surf, 160)
+    ora.map_upload(surf, 160)
+    T0 = get_scan(0, 900, True)[3]
+    pose_prior = np.linalg.inv(T0) @ get_scan(2, 900, True)[3]        # an "old" pose near the revisit
+    cur_pose = np.linalg.inv(T0) @ get_scan(3, 900, True)[3]
+    pts, lab, prob, _ = get_scan(3, 900, True)
+    hf = hip.Frame(ctx, 900, 64)
+    hip.Preprocessing(ctx).process(pts, hf, lab, prob, 160)
+    of = ora.preprocess(pts, lab, prob, 160, ora.frame())
+    O = np.linalg.inv(pose_prior) @ cur_pose
+    O[2, 3] = 0.0
+    Rz = O.copy()
+    Rz[:2, :2] = -Rz[:2, :2]                                          # second guess: rotated by 180 degrees
+    half = O.copy()
+    half[:2, 3] *= 0.5
+    inits = [O, Rz, half]
+    ct = -1.0
+    res = hip.loop_closure_verify(ctx, hf, pose_prior, inits, cur_pose, ct)
+    # the same sequence on the oracle
+    ora.map_render_inactive(pose_prior.astype(np.float32), ct)
+    model = ora.map_frame(0)
+    n_passed = 0
+    for k, init in enumerate(inits):
+        T, _, st = ora.minimize(of, model, init)
+        it = st.iterations + (1 if st.converged else 0)
+        _, _, _, _, s0 = ora.jacobian_products(of, model, T, it)
+        assert np.array_equal(res[k]["gn_pose"], T), f"guess {k} pose"
+        a = res[k]["after_minimize"]
+        assert (a["valid"], a["outlier"], a["inlier"], a["invalid"], a["error"]) == (s0.valid, s0.outlier, s0.inlier, s0.invalid, s0.error)
+        valid_ratio = np.float32(s0.valid) / np.float32(s0.valid + s0.invalid)
+        outlier_ratio = np.float32(s0.outlier) / np.float32(s0.outlier + s0.inlier)
+        passed = bool(valid_ratio > np.float32(0.2) and outlier_ratio < np.float32(0.85))
+        assert res[k]["passed"] == passed
+        pose_old = (pose_prior @ T).astype(np.float32)
+        assert np.array_equal(res[k]["pose_old"], pose_old)
+        if passed:
+            n_passed += 1
+            ora.map_render_composed(pose_old, cur_pose.astype(np.float32), ct)
+            model = ora.map_frame(2)   # the reference leaves the objective on the composed frame
+            Fc, _, JtJ, _, sc = ora.jacobian_products(of, model, np.eye(4), 0)
+            c = res[k]["composed"]
+            assert (c["valid"], c["outlier"], c["invalid"], c["error"]) == (sc.valid, sc.outlier, sc.invalid, sc.error)
+            assert np.array_equal(res[k]["JtJ"], JtJ)
+    assert n_passed >= 1, "test setup: at least one guess should pass the gates"
