@@ -284,7 +284,7 @@ __device__ __forceinline__ void store_surfel(suma_surfel* out, uint32_t idx, con
  * surviving surfel marks that measurement pixel as integrated */
 __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surfel4& o, int32_t* mark_pix) {
   const int32_t timestamp = a.timestamp;
-  const int32_t W = a.q.W, H = a.q.H;
+  const int32_t W = a.q.W;
   const int32_t surfel_age = timestamp - (int32_t)__float_as_uint(in.c.x);
   const int32_t creation_timestamp = (int32_t)in.c.w;
   float Ps[16];
