@@ -83,12 +83,12 @@ __device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t 
 }
 
 /* One triangle at one pixel centre: coverage (top-left style ownership rule), affine interpolation
- * of depth and disc coordinates, disc + near/far tests, depth-tested write.  Every quantity is a
- * function of the triangle and the pixel only, so the work can be distributed freely over lanes. */
-__device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, int32_t j, int32_t W,
-                                             unsigned long long* __restrict__ zbuf, uint32_t id, int tie) {
+ * of depth and disc coordinates, disc + near/far tests.  Returns the z-buffer key of the fragment or
+ * SUMA_EMPTY_KEY if the triangle produces none.  Every quantity is a function of the triangle and the
+ * pixel only, so the work can be distributed freely over lanes. */
+__device__ __forceinline__ unsigned long long raster_key(rvtx A, rvtx B, rvtx C, int32_t i, int32_t j, uint32_t id,
+                                                         int tie) {
   long long area = edge_fn(A, B, C.X, C.Y);
-  if (area == 0) return;
   if (area < 0) {
     rvtx t = B;
     B = C;
@@ -97,17 +97,19 @@ __device__ __forceinline__ void raster_pixel(rvtx A, rvtx B, rvtx C, int32_t i, 
   }
   const int32_t px = 256 * i + 128, py = 256 * j + 128;
   const long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
-  if (!(w0 > 0 || (w0 == 0 && owns_edge(B, C)))) return;
-  if (!(w1 > 0 || (w1 == 0 && owns_edge(C, A)))) return;
-  if (!(w2 > 0 || (w2 == 0 && owns_edge(A, B)))) return;
-  const float fa = (float)area;
-  float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
-  float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
-  float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
-  if ((tu * tu + tv * tv) > 1.0f) return; /* render_surfels.frag:22 */
-  float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
-  if (!(z >= 0.0f && z <= 1.0f)) return; /* near / far clipping */
-  zbuf_min(&zbuf[(size_t)j * (size_t)W + (size_t)i], render_key(depth24(z), id, tie));
+  const bool covered = (area != 0) & (w0 > 0 || (w0 == 0 && owns_edge(B, C))) &
+                       (w1 > 0 || (w1 == 0 && owns_edge(C, A))) & (w2 > 0 || (w2 == 0 && owns_edge(A, B)));
+  unsigned long long key = SUMA_EMPTY_KEY;
+  if (covered) {
+    const float fa = (float)area;
+    float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+    float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
+    float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
+    float z = (b0 * A.z + b1 * B.z) + b2 * C.z;
+    /* render_surfels.frag:22 disc test; near / far clipping */
+    if (!((tu * tu + tv * tv) > 1.0f) && (z >= 0.0f && z <= 1.0f)) key = render_key(depth24(z), id, tie);
+  }
+  return key;
 }
 
 /* (inv_pose * surfelPose) * v, render_surfels.vert:44-48 */
@@ -142,6 +144,8 @@ __device__ __forceinline__ void surfel_to_sensor(const float* __restrict__ poses
  *                         the work it contained. */
 #define RENDER_THREADS 256
 #define RENDER_WAVES (RENDER_THREADS / 64)
+#define RENDER_BATCH 4
+#define SUMA_RENDER_MAX_BLOCKS 65536u
 
 /* exclusive rank of `flag` among the block's threads + block total (all threads call) */
 __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, uint32_t* total) {
@@ -160,7 +164,7 @@ __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, 
   return off + __popcll(ball & ((1ull << lane) - 1ull));
 }
 
-__global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
+__global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
   __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
   __shared__ int32_t s_rec[RENDER_THREADS][16]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id */
   __shared__ uint32_t s_incl[RENDER_THREADS];
@@ -190,6 +194,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
       const bool selected = live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr));
       const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
       bool cand = false;
+      unsigned long long k7_key = SUMA_EMPTY_KEY;
+      uint32_t k7_pix = 0;
       v3 p = mk3(0, 0, 0), n = p;
       float ppx = 0.f;
       if (selected || k7) {
@@ -204,8 +210,9 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
             float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
             float zn = 2.0f * pr.z - 1.0f;
             if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
-              unsigned long long key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
-              zbuf_min(&a.k7_zbuf[(size_t)(int32_t)fy * a.k7_q.W + (size_t)(int32_t)fx], key);
+              /* depth-tested write deferred to phase 2, where its memory round trip overlaps the raster's */
+              k7_key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
+              k7_pix = (uint32_t)(int32_t)fy * (uint32_t)a.k7_q.W + (uint32_t)(int32_t)fx;
             }
           }
           if (selected) {
@@ -318,37 +325,66 @@ __global__ void __launch_bounds__(RENDER_THREADS) k_render(RenderArgs a) {
       s_incl[threadIdx.x] = incl + woff;
       __syncthreads();
       /* ---- phase 2 ---- */
-      for (uint32_t t = threadIdx.x; t < total; t += RENDER_THREADS) {
-        /* source record: the first one whose inclusive prefix exceeds t */
-        int lo = 0, hi = RENDER_THREADS - 1;
+      /* Four tests per lane and trip: the fragments' keys are computed first, then the (device-coherent,
+       * i.e. memory-side) z-buffer reads of all four are in flight together and the atomics follow --
+       * one memory round trip per 1024 tests instead of two per 256.  The two strip triangles of a quad
+       * write the same pixel, so their keys are min-combined into a single depth-tested write. */
+      unsigned long long k7_cur = 0;
+      if (k7_key != SUMA_EMPTY_KEY)
+        k7_cur = __hip_atomic_load(&a.k7_zbuf[k7_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (uint32_t t0 = threadIdx.x; t0 < total; t0 += RENDER_BATCH * RENDER_THREADS) {
+        unsigned long long key[RENDER_BATCH];
+        uint32_t pix[RENDER_BATCH];
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          int mid = (lo + hi) >> 1;
-          if (s_incl[mid] > t)
-            hi = mid;
-          else
-            lo = mid + 1;
-        }
-        const int src = lo;
-        const uint32_t excl = src ? s_incl[src - 1] : 0u;
-        const int32_t* r = s_rec[src];
-        const uint32_t q = t - excl, w = (uint32_t)r[14];
-        const uint32_t qj = q / w, qi = q - qj * w;
-        const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
-        rvtx vt[4];
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          const uint32_t t = t0 + (uint32_t)u * RENDER_THREADS;
+          key[u] = SUMA_EMPTY_KEY;
+          pix[u] = 0;
+          if (t < total) {
+            /* source record: the first one whose inclusive prefix exceeds t */
+            int lo = 0, hi = RENDER_THREADS - 1;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          vt[k].X = r[k];
-          vt[k].Y = r[4 + k];
-          vt[k].z = __int_as_float(r[8 + k]);
-          vt[k].tu = (k & 1) ? 1.0f : -1.0f;
-          vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+            for (int it = 0; it < 8; ++it) {
+              int mid = (lo + hi) >> 1;
+              if (s_incl[mid] > t)
+                hi = mid;
+              else
+                lo = mid + 1;
+            }
+            const int src = lo;
+            const uint32_t excl = src ? s_incl[src - 1] : 0u;
+            const int32_t* r = s_rec[src];
+            const uint32_t q = t - excl, w = (uint32_t)r[14];
+            const uint32_t qj = q / w, qi = q - qj * w;
+            const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
+            rvtx vt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              vt[k].X = r[k];
+              vt[k].Y = r[4 + k];
+              vt[k].z = __int_as_float(r[8 + k]);
+              vt[k].tu = (k & 1) ? 1.0f : -1.0f;
+              vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+            }
+            const uint32_t id = (uint32_t)r[15];
+            /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
+            const unsigned long long ka = raster_key(vt[0], vt[1], vt[2], pi, pj, id, slot.tie);
+            const unsigned long long kb = raster_key(vt[2], vt[1], vt[3], pi, pj, id, slot.tie);
+            key[u] = ka < kb ? ka : kb;
+            pix[u] = (uint32_t)pj * (uint32_t)a.q.W + (uint32_t)pi;
+          }
         }
-        const uint32_t id = (uint32_t)r[15];
-        /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
-        raster_pixel(vt[0], vt[1], vt[2], pi, pj, a.q.W, slot.zbuf, id, slot.tie);
-        raster_pixel(vt[2], vt[1], vt[3], pi, pj, a.q.W, slot.zbuf, id, slot.tie);
+        unsigned long long cur[RENDER_BATCH];
+#pragma unroll
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          cur[u] = 0;
+          if (key[u] != SUMA_EMPTY_KEY) cur[u] = __hip_atomic_load(&slot.zbuf[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int u = 0; u < RENDER_BATCH; ++u)
+          if (key[u] < cur[u]) atomicMin(&slot.zbuf[pix[u]], key[u]);
       }
+      if (k7_key < k7_cur) atomicMin(&a.k7_zbuf[k7_pix], k7_key);
       __syncthreads(); /* the LDS lists are reused by the next slot / iteration */
     }
   }
@@ -476,7 +512,10 @@ static uint32_t stream_grid(suma_ctx* c) {
    * device-resident count, so a stale value only changes the number of loop trips */
   uint64_t est = (uint64_t)c->known_surfels + 2 * c->P;
   uint64_t blocks = (est + 255) / 256;
-  if (blocks > SUMA_STREAM_BLOCKS) blocks = SUMA_STREAM_BLOCKS;
+  /* one tile per block while that stays a sane grid: the per-tile cost varies several-fold (pixel tests),
+   * and the hardware dispatcher balances single-tile blocks for free; very large maps fall back to
+   * grid-striding */
+  if (blocks > SUMA_RENDER_MAX_BLOCKS) blocks = SUMA_RENDER_MAX_BLOCKS;
   if (blocks < 256) blocks = 256;
   return (uint32_t)blocks;
 }
