@@ -280,17 +280,66 @@ __device__ __forceinline__ void store_surfel(suma_surfel* out, uint32_t idx, con
   o[3] = s.d;
 }
 
-/* K9 for one surfel: returns keep; `o` receives the updated record; *mark_pix >= 0 if the
- * surviving surfel marks that measurement pixel as integrated */
-__device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surfel4& o, int32_t* mark_pix) {
+/* K9 for one surfel, in three stages so that a lane can keep TWO surfels in flight (the stages are
+ * separated by dependent loads: surfel -> pose table entry -> measurement record):
+ *   k9_prepare  surfel + pose entry  -> world / sensor frame quantities, projection, texel address
+ *   k9_gather   the measurement record (one 64-byte line, built by K8) + the K7 key of that pixel
+ *   k9_finish   update_surfels.vert proper; returns keep, `o` receives the updated record,
+ *               *mark_pix >= 0 if the surviving surfel marks that measurement pixel as integrated */
+struct K9Pre {
+  v3 old_position, old_normal;
+  float imz;
+  int32_t tx, ty;
+  uint32_t rpix;
+  bool in_tex, visible, inside;
+};
+struct K9Rec {
+  float4 dv, dn, dx;
+  unsigned long long k7key;
+};
+
+__device__ __forceinline__ K9Pre k9_prepare(const UpdArgs& a, const Surfel4& in) {
+  K9Pre p;
+  const int32_t creation_timestamp = (int32_t)in.c.w;
+  float Ps[16];
+  load_pose(a.poses, creation_timestamp, Ps);
+  p.old_position = m4_point(Ps, xyz(in.a));
+  p.old_normal = m4_dir(Ps, xyz(in.b));
+  const v3 vertex = m4_point(a.inv_pose.m, p.old_position);
+  const v3 normal = normalize3(m4_dir(a.inv_pose.m, p.old_normal));
+  p.visible = dot3(normal, divs3(neg3(vertex), len3(vertex))) > 0.0f;
+  const v3 pr = project01(a.q, vertex);
+  const float imx = sdm_floor(pr.x * a.q.width) + 0.5f, imy = sdm_floor(pr.y * a.q.height) + 0.5f;
+  p.imz = pr.z;
+  /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
+  p.in_tex = (imx >= 0.0f && imx < a.q.width && imy >= 0.0f && imy < a.q.height);
+  p.tx = p.in_tex ? (int32_t)sdm_floor(imx) : -1;
+  p.ty = p.in_tex ? (int32_t)sdm_floor(imy) : -1;
+  p.rpix = (uint32_t)max(p.ty, 0) * (uint32_t)a.q.W + (uint32_t)max(p.tx, 0);
+  /* quirk B-6: all(lessThan(img, dim)) && !all(lessThan(img, 0)) */
+  p.inside = (imx < a.q.width && imy < a.q.height && p.imz < 1.0f) && !(imx < 0.0f && imy < 0.0f && p.imz < 0.0f);
+  return p;
+}
+
+/* one 64-byte line per measurement pixel (built by K8): vertex, normal, (label, prob, radius);
+ * border (0) outside the image or for NaN coordinates, as the NEAREST / CLAMP_TO_BORDER fetch */
+__device__ __forceinline__ K9Rec k9_gather(const UpdArgs& a, const K9Pre& p) {
+  K9Rec r;
+  const float4* __restrict__ rec = a.pixrec + 4 * (size_t)p.rpix;
+  r.dv = rec[0];
+  r.dn = rec[1];
+  r.dx = rec[2];
+  r.k7key = a.zbuf[p.rpix];
+  return r;
+}
+
+__device__ __forceinline__ bool k9_finish(const UpdArgs& a, uint32_t i, const Surfel4& in, const K9Pre& p,
+                                          const K9Rec& g, Surfel4& o, int32_t* mark_pix) {
   const int32_t timestamp = a.timestamp;
   const int32_t W = a.q.W;
   const int32_t surfel_age = timestamp - (int32_t)__float_as_uint(in.c.x);
   const int32_t creation_timestamp = (int32_t)in.c.w;
-  float Ps[16];
-  load_pose(a.poses, creation_timestamp, Ps);
-  const v3 old_position = m4_point(Ps, xyz(in.a));
-  const v3 old_normal = m4_dir(Ps, xyz(in.b));
+  const v3 old_position = p.old_position, old_normal = p.old_normal;
   const float old_radius = in.a.w, old_confidence = in.b.w, old_weight = in.c.z;
 
   bool keep = true;
@@ -298,32 +347,19 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
   o = in;
   o.c.y = pack_rgb(0.3f, 0.3f, 0.3f);
 
-  const v3 vertex = m4_point(a.inv_pose.m, old_position);
-  const v3 normal = normalize3(m4_dir(a.inv_pose.m, old_normal));
-  const bool visible = dot3(normal, divs3(neg3(vertex), len3(vertex))) > 0.0f;
-  const v3 pr = project01(a.q, vertex);
-  const float imx = sdm_floor(pr.x * a.q.width) + 0.5f, imy = sdm_floor(pr.y * a.q.height) + 0.5f, imz = pr.z;
-  /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
-  const bool in_tex = (imx >= 0.0f && imx < a.q.width && imy >= 0.0f && imy < a.q.height);
-  const int32_t tx = in_tex ? (int32_t)sdm_floor(imx) : -1, ty = in_tex ? (int32_t)sdm_floor(imy) : -1;
-  /* one 64-byte line per measurement pixel (built by K8): vertex, normal, (label, prob, radius);
-   * border (0) outside the image or for NaN coordinates, as the NEAREST / CLAMP_TO_BORDER fetch */
-  const size_t rpix = (size_t)max(ty, 0) * W + (size_t)max(tx, 0);
-  const float4* __restrict__ rec = a.pixrec + 4 * rpix;
-  float4 dv = rec[0], dn = rec[1], dx = rec[2];
-  if (!in_tex) dv = dn = dx = f4(0.f, 0.f, 0.f, 0.f);
+  float4 dv = g.dv, dn = g.dn, dx = g.dx;
+  if (!p.in_tex) dv = dn = dx = f4(0.f, 0.f, 0.f, 0.f);
   const float4 ds = f4(dx.x, 0.f, 0.f, dx.y), rc = f4(dx.z, 0.f, 0.f, 0.f);
-  const unsigned long long k7key = a.zbuf[rpix];
+  const unsigned long long k7key = g.k7key;
   const bool valid = (dv.w > 0.5f) && (dn.w > 0.5f);
-  /* quirk B-6: all(lessThan(img, dim)) && !all(lessThan(img, 0)) */
-  const bool inside =
-      (imx < a.q.width && imy < a.q.height && imz < 1.0f) && !(imx < 0.0f && imy < 0.0f && imz < 0.0f);
+  const float imz = p.imz;
+  const int32_t tx = p.tx, ty = p.ty;
 
   float penalty = 0.0f;
   float update_confidence = a.log_prior;
   bool mark = false;
 
-  if (valid && inside && visible) {
+  if (valid && p.inside && p.visible) {
     const float data_label = ds.x * 255.0f, data_prob = ds.w;
     const float model_label = in.d.x * 255.0f, model_prob = in.d.w;
     if (sdm_round(data_label) != sdm_round(model_label)) {
@@ -415,108 +451,142 @@ __device__ bool update_one(const UpdArgs& a, uint32_t i, const Surfel4& in, Surf
   return keep;
 }
 
-/* K9 (+ K11 predicate): single-pass update with stable compaction.  Tiles of 256 surfels are
- * handed out by ticket; output offset by decoupled look-back. */
-/* Tiles are processed in PAIRS per block: compute tile A (survivors staged in LDS, count published),
- * compute tile B (same), and only then wait for A's output offset, stream A out, wait for B's, stream
- * B out.  A tile's offset depends on every earlier tile of the launch having published its count, so
- * waiting right after the compute exposes each block to the slowest of the ~256 tiles in flight
- * ahead of it (head-of-line blocking, 24 us per tile independent of occupancy); with the wait
- * deferred behind the next tile's compute it is almost always already satisfied.  A block never
- * waits before it has published the counts of both of its tiles, so there is no circular wait.
- * The LDS staging also turns the 64-byte-strided record stores into a dense 16 B-per-lane stream. */
-#define K9_PAIR 2u
-__global__ void __launch_bounds__(SUMA_TILE) k9_update(UpdArgs a) {
-  __shared__ float4 s_out[K9_PAIR][SUMA_TILE][4];
-  __shared__ uint32_t s_cnt_emit[TILE_WAVES], s_cnt_keep[TILE_WAVES];
+/* K9 (+ K11 predicate): single-pass update with stable compaction, tiles of SUMA_TILE surfels handed
+ * out by ticket, output offset by the two-level look-back above.
+ *
+ * The per-surfel work is a chain of dependent memory round trips (surfel -> pose entry -> measurement
+ * record) with divergent arithmetic at the end, so the kernel is organised for latency, not bandwidth:
+ *  - 512-thread blocks, TWO surfels per lane with the stages of both interleaved (twice the loads in
+ *    flight per wave), 64 KB of LDS -> two blocks per CU that run out of phase: while one sits in its
+ *    barrier / look-back wait the other computes;
+ *  - a lane drops its updated record into LDS at its own (uncompacted) slot as soon as it is computed;
+ *    the stable ranks follow from two ballots and a rank -> slot table, and the stream-out walks that
+ *    table, writing a dense 16 B-per-lane stream instead of 64-byte-strided record stores;
+ *  - the barriers are LDS-only (no vmcnt drain): the fire-and-forget stores (integration mask, status
+ *    words, the previous tile's stream-out) stay in flight across them. */
+#define K9_THREADS 512
+#define K9_WAVES (K9_THREADS / 64)
+static_assert(SUMA_TILE == 2 * K9_THREADS, "K9 processes two surfels per lane");
+
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, uint32_t i) {
+  Surfel4 r;
+  r.a = sf[4 * (size_t)i];
+  r.b = sf[4 * (size_t)i + 1];
+  r.c = sf[4 * (size_t)i + 2];
+  r.d = sf[4 * (size_t)i + 3];
+  return r;
+}
+
+__global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
+  __shared__ float4 s_out[2][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
+  __shared__ uint16_t s_slot[2][SUMA_TILE]; /* stable rank -> slot */
+  __shared__ uint32_t s_cnt_emit[2][K9_WAVES], s_cnt_keep[K9_WAVES];
   __shared__ uint32_t s_tile, s_prefix;
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
-  const uint32_t npairs = (ntiles + K9_PAIR - 1) / K9_PAIR; /* tickets are handed out per pair */
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
   float4* __restrict__ dst4 = reinterpret_cast<float4*>(a.out);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_count = 0; /* thread 0: survivors before the area filter (S') */
+  /* the tile whose records wait in LDS for their output offset */
+  uint32_t prev_tile = 0xffffffffu, prev_total = 0, buf = 0;
   for (;;) {
-    __syncthreads();
+    lds_barrier(); /* s_tile / s_prefix / s_cnt_* of the previous trip have been read */
     if (threadIdx.x == 0)
       s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    const uint32_t pair = s_tile;
-    if (pair >= npairs) break;
-    uint32_t total[K9_PAIR];
-#pragma unroll 1
-    for (uint32_t h = 0; h < K9_PAIR; ++h) {
-      const uint32_t tile = pair * K9_PAIR + h;
-      total[h] = 0;
-      if (tile >= ntiles) break; /* block-uniform */
-      const uint32_t i = tile * SUMA_TILE + threadIdx.x;
-      bool keep = false, emit = false;
-      Surfel4 o;
-      if (i < S) {
-        Surfel4 in;
-        in.a = sf[4 * (size_t)i];
-        in.b = sf[4 * (size_t)i + 1];
-        in.c = sf[4 * (size_t)i + 2];
-        in.d = sf[4 * (size_t)i + 3];
+    lds_barrier();
+    const uint32_t tile = s_tile;
+    uint32_t total = 0;
+    if (tile < ntiles) {
+      const uint32_t slot0 = threadIdx.x, slot1 = K9_THREADS + threadIdx.x;
+      const uint32_t i0 = tile * SUMA_TILE + slot0, i1 = tile * SUMA_TILE + slot1;
+      const bool live0 = i0 < S, live1 = i1 < S;
+      /* out-of-range lanes read surfel 0 (S > 0 here) and are masked at the end */
+      const Surfel4 in0 = load_surfel(sf, live0 ? i0 : 0u), in1 = load_surfel(sf, live1 ? i1 : 0u);
+      const K9Pre p0 = k9_prepare(a, in0), p1 = k9_prepare(a, in1);
+      const K9Rec g0 = k9_gather(a, p0), g1 = k9_gather(a, p1);
+      bool keep0, keep1, emit0, emit1;
+      {
+        Surfel4 o;
         int32_t mark_pix;
-        keep = update_one(a, i, in, o, &mark_pix);
-        if (mark_pix >= 0) a.integrated[mark_pix] = 1;
-        emit = keep && in_active_area(a, o);
+        keep0 = k9_finish(a, i0, in0, p0, g0, o, &mark_pix) && live0;
+        if (keep0 && mark_pix >= 0) a.integrated[mark_pix] = 1;
+        emit0 = keep0 && in_active_area(a, o);
+        s_out[buf][slot0][0] = o.a;
+        s_out[buf][slot0][1] = o.b;
+        s_out[buf][slot0][2] = o.c;
+        s_out[buf][slot0][3] = o.d;
       }
-      const unsigned long long kb = __ballot(keep), eb = __ballot(emit);
+      {
+        Surfel4 o;
+        int32_t mark_pix;
+        keep1 = k9_finish(a, i1, in1, p1, g1, o, &mark_pix) && live1;
+        if (keep1 && mark_pix >= 0) a.integrated[mark_pix] = 1;
+        emit1 = keep1 && in_active_area(a, o);
+        s_out[buf][slot1][0] = o.a;
+        s_out[buf][slot1][1] = o.b;
+        s_out[buf][slot1][2] = o.c;
+        s_out[buf][slot1][3] = o.d;
+      }
+      const unsigned long long eb0 = __ballot(emit0), eb1 = __ballot(emit1);
+      const uint32_t kept = __popcll(__ballot(keep0)) + __popcll(__ballot(keep1));
       if (lane == 0) {
-        s_cnt_keep[wave] = __popcll(kb); /* S' statistics (parity with the reference's TF count) */
-        s_cnt_emit[wave] = __popcll(eb);
+        s_cnt_keep[wave] = kept; /* S' statistics (parity with the reference's TF count) */
+        s_cnt_emit[0][wave] = __popcll(eb0);
+        s_cnt_emit[1][wave] = __popcll(eb1);
       }
-      __syncthreads();
-      uint32_t off = 0, tot = 0, kc = 0;
+      lds_barrier();
+      uint32_t off0 = 0, off1 = 0, tot0 = 0, tot1 = 0, kc = 0;
 #pragma unroll
-      for (int w = 0; w < (int)TILE_WAVES; ++w) {
-        const uint32_t cnt = s_cnt_emit[w];
-        if (w < wave) off += cnt;
-        tot += cnt;
+      for (int w = 0; w < K9_WAVES; ++w) {
+        const uint32_t c0 = s_cnt_emit[0][w], c1 = s_cnt_emit[1][w];
+        if (w < wave) {
+          off0 += c0;
+          off1 += c1;
+        }
+        tot0 += c0;
+        tot1 += c1;
         kc += s_cnt_keep[w];
       }
-      total[h] = tot;
-      if (threadIdx.x == 0) keep_count += kc;
-      if (emit) { /* stage at the block-local compacted position */
-        const uint32_t r = off + __popcll(eb & ((1ull << lane) - 1ull));
-        s_out[h][r][0] = o.a;
-        s_out[h][r][1] = o.b;
-        s_out[h][r][2] = o.c;
-        s_out[h][r][3] = o.d;
+      total = tot0 + tot1;
+      if (threadIdx.x == 0) {
+        keep_count += kc;
+        lookback_publish(a.status, a.group, tile, total, a.epoch);
       }
-      /* publish the count now; the offset is collected later */
-      if (threadIdx.x == 0) lookback_publish(a.status, a.group, tile, tot, a.epoch);
-      __syncthreads(); /* s_cnt_* are reused by the next tile of the pair */
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (emit0) s_slot[buf][off0 + __popcll(eb0 & below)] = (uint16_t)slot0;
+      if (emit1) s_slot[buf][tot0 + off1 + __popcll(eb1 & below)] = (uint16_t)slot1;
     }
-#pragma unroll 1
-    for (uint32_t h = 0; h < K9_PAIR; ++h) {
-      const uint32_t tile = pair * K9_PAIR + h;
-      if (tile >= ntiles) break;
+    /* the PREVIOUS tile's offset: every tile before it was drawn before it and is published without
+     * any wait in between, and this block has published everything it holds -- no circular wait; by
+     * now (one tile's compute later) the words are almost always there */
+    if (prev_tile != 0xffffffffu) {
       if (threadIdx.x < 64) {
-        uint32_t pre = lookback_collect(a.status, a.group, tile, a.epoch, threadIdx.x, &a.ds->overflow);
+        const uint32_t pre = lookback_collect(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
         if (threadIdx.x == 0) s_prefix = pre;
       }
-      __syncthreads();
-      const uint32_t prefix = s_prefix;
+      lds_barrier();
+      const uint32_t prefix = s_prefix, pb = buf ^ 1u;
       /* compacted stream-out: chunk c = (rank, 16-byte part) */
-      const float4* __restrict__ src = &s_out[h][0][0];
-      for (uint32_t c = threadIdx.x; c < 4u * total[h]; c += SUMA_TILE) {
+      for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
         const uint64_t d = 4ull * prefix + c;
-        if (d < 4ull * a.max_surfels) dst4[d] = src[c];
+        if (d < 4ull * a.max_surfels) dst4[d] = s_out[pb][s_slot[pb][c >> 2]][c & 3u];
       }
-      if (tile == ntiles - 1 && threadIdx.x == 0) {
-        uint32_t tot = prefix + total[h];
+      if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
+        const uint32_t tot = prefix + prev_total;
         a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
       }
-      __syncthreads(); /* s_prefix is reused */
     }
+    if (tile >= ntiles) break;
+    prev_tile = tile;
+    prev_total = total;
+    buf ^= 1u;
   }
   if (threadIdx.x == 0 && keep_count)
     __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (is_finaliser(s_tile, npairs)) {
+  if (is_finaliser(s_tile, ntiles)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
     if (threadIdx.x == 0 && ntiles == 0) a.ds->n_kept_updated = 0;
   }
@@ -706,7 +776,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     a.epoch = ++c->epoch;
     a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
     a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
-    k9_update<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + 1) / 2), SUMA_TILE, 0, st>>>(a);
+    k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), K9_THREADS, 0, st>>>(a);
   }
   {
     ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);
