@@ -148,6 +148,11 @@ __device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
   out[15] = 1.0f;
 }
 
+/* Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding global
+ * load / store / atomic of the wave (s_waitcnt vmcnt(0)), which turns loads issued early on purpose and
+ * fire-and-forget stores into stalls.  Use where the data exchanged across the barrier lives in LDS. */
+SDEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #define SUMA_EMPTY_KEY (~0ull)
 
 /* Depth-tested write into a 64-bit z-buffer (key = depth24 << 32 | id, smaller wins).  A pixel that many

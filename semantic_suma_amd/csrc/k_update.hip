@@ -468,8 +468,6 @@ __device__ __forceinline__ bool k9_finish(const UpdArgs& a, uint32_t i, const Su
 #define K9_WAVES (K9_THREADS / 64)
 static_assert(SUMA_TILE == 2 * K9_THREADS, "K9 processes two surfels per lane");
 
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, uint32_t i) {
   Surfel4 r;
   r.a = sf[4 * (size_t)i];
