@@ -97,8 +97,8 @@ __device__ __forceinline__ unsigned long long raster_key(rvtx A, rvtx B, rvtx C,
   }
   const int32_t px = 256 * i + 128, py = 256 * j + 128;
   const long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
-  const bool covered = (area != 0) & (w0 > 0 || (w0 == 0 && owns_edge(B, C))) &
-                       (w1 > 0 || (w1 == 0 && owns_edge(C, A))) & (w2 > 0 || (w2 == 0 && owns_edge(A, B)));
+  const bool covered = (area != 0) && (w0 > 0 || (w0 == 0 && owns_edge(B, C))) &&
+                       (w1 > 0 || (w1 == 0 && owns_edge(C, A))) && (w2 > 0 || (w2 == 0 && owns_edge(A, B)));
   unsigned long long key = SUMA_EMPTY_KEY;
   if (covered) {
     const float fa = (float)area;
