@@ -247,6 +247,10 @@ struct IterArgs {
   int emit_pose;
   PoseD pose_base;
   float* pose_block; /* 16 floats pose, 16 floats inverse */
+  /* closing launch: report to the host directly (pinned memory), see HostResult */
+  HostResult* host_out;
+  uint32_t host_seq;
+  const DevState* ds;
 };
 
 /* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
@@ -472,6 +476,21 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
           g.pose_block[16 + i] = Pinv[i];
         }
       }
+      if (!PIXEL && g.host_out != nullptr && blockIdx.y == 0) {
+        HostResult* __restrict__ h = g.host_out;
+        for (int i = 0; i < 16; ++i) h->Tk[i] = Tk[i];
+        h->F = gout->F; /* own earlier stores (every branch above leaves gout complete) */
+        h->F_inlier = gout->F_inlier;
+        h->valid = gout->valid;
+        h->outlier = gout->outlier;
+        h->invalid = gout->invalid;
+        h->k = gout->k;
+        h->converged = gout->converged;
+        h->iteration = gout->iteration;
+        h->ds = *g.ds;
+        __threadfence_system();
+        __hip_atomic_store(&h->seq, g.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     return;
   }
@@ -663,6 +682,9 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.emit_pose = (!pixel && c->gn_emit_pose) ? 1 : 0;
   for (int i = 0; i < 16; ++i) g.pose_base.m[i] = c->gn_pose_base[i];
   g.pose_block = c->pose_block;
+  g.host_out = pixel ? nullptr : c->gn_host_out;
+  g.host_seq = c->gn_host_seq;
+  g.ds = c->ds;
   g.init = c->gn_init_pending;
   g.iteration0 = c->gn_iteration0;
   for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];

@@ -288,6 +288,8 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->pose_block, 32 * sizeof(float)));
     CK(hipEventCreateWithFlags(&c->ev_result, hipEventDisableTiming));
     c->gn_emit_pose = 0;
+    c->gn_host_out = nullptr;
+    c->gn_host_seq = 0;
     /* submap cache arena */
     /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
      * trajectory stays parked in HBM; re-extracted tiles take fresh arena space */
@@ -481,6 +483,34 @@ static void fill_stats(const GnState& g, suma_icp_stats* st) {
   st->invalid = g.invalid;
   st->iterations = g.k;
   st->converged = g.converged;
+}
+
+static void fill_stats_host(const HostResult& g, suma_icp_stats* st) {
+  if (!st) return;
+  st->error = g.F;
+  st->inlier_residual = g.F_inlier;
+  st->valid = g.valid;
+  st->outlier = g.outlier;
+  st->inlier = g.valid - g.outlier;
+  st->invalid = g.invalid;
+  st->iterations = g.k;
+  st->converged = g.converged;
+}
+
+/* Poll a HostResult until the closing launch has stamped it.  The stream is queried now and then so that
+ * a faulted or drained stream surfaces as an error instead of an endless spin. */
+static int wait_host_result(suma_ctx* c, const HostResult* h, uint32_t seq) {
+  for (uint32_t spins = 1;; ++spins) {
+    if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return SUMA_OK;
+    if ((spins & 0xfffu) == 0) {
+      hipError_t q = hipStreamQuery(c->stream);
+      if (q == hipSuccess) { /* everything has run: the record must be there */
+        if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return SUMA_OK;
+        return fail(c, SUMA_ERR_HIP, "minimisation result was not reported");
+      }
+      if (q != hipErrorNotReady) CK(q);
+    }
+  }
 }
 
 extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], uint32_t iteration, double JtJ[36],
@@ -936,11 +966,13 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
       return r;
     }
   }
-  if (hipHostMalloc((void**)&s->h_stats, 2 * sizeof(GnState), hipHostMallocDefault) != hipSuccess) {
+  if (hipHostMalloc((void**)&s->h_res, 3 * sizeof(HostResult), hipHostMallocDefault) != hipSuccess) {
     g_create_error = "hipHostMalloc failed";
     suma_pipeline_destroy(s);
     return SUMA_ERR_HIP;
   }
+  memset(s->h_res, 0, 3 * sizeof(HostResult));
+  s->res_seq = 0;
   s->stats_pending = false;
   s->stats_slot = 0;
   eye_d(s->current_pose);
@@ -960,7 +992,7 @@ extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
   suma_frame_destroy(s->current_frame);
   suma_frame_destroy(s->current_model);
   suma_frame_destroy(s->last_model);
-  if (s->h_stats) hipHostFree(s->h_stats);
+  if (s->h_res) hipHostFree(s->h_res);
   suma_ctx_destroy(s->c);
   delete s;
 }
@@ -992,7 +1024,13 @@ static void resolve_stats(suma_pipeline* s, bool need_sync) {
   if (!s->stats_pending) return;
   if (need_sync) hipStreamSynchronize(s->c->stream);
   suma_icp_stats st;
-  fill_stats(s->h_stats[s->stats_slot], &st);
+  const HostResult& hr = s->h_res[1 + s->stats_slot];
+  /* written by a launch that precedes, in stream order, either the synchronisation above or the
+   * minimisation result the caller has just received */
+  while (__atomic_load_n(&hr.seq, __ATOMIC_ACQUIRE) != s->stats_seq) {
+    if (hipStreamQuery(s->c->stream) != hipErrorNotReady && __atomic_load_n(&hr.seq, __ATOMIC_ACQUIRE) != s->stats_seq) break;
+  }
+  fill_stats_host(hr, &st);
   st.iterations = s->stats_mst.iterations;
   st.converged = s->stats_mst.converged;
   s->stats = st;
@@ -1065,13 +1103,14 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
     c->icp_model = c->new_frame;
     c->gn_emit_pose = 1;
     memcpy(c->gn_pose_base, s->pose_new, sizeof(c->gn_pose_base));
+    s->res_seq += 1;
+    c->gn_host_out = &s->h_res[0]; /* the closing launch reports straight into pinned host memory */
+    c->gn_host_seq = s->res_seq;
     int r0 = enqueue_minimize(c, T0, 1, 0);
     c->gn_emit_pose = 0;
+    c->gn_host_out = nullptr;
     c->p = saved;
     if (r0) return r0;
-    CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-    CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
-    CK(hipEventRecord(c->ev_result, c->stream));
   }
   /* --- re-render from pose_new * increment (pose taken from HBM), K7 splat and the
    *     lastModelFrame copy fused in (:406-407) --- */
@@ -1087,26 +1126,28 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
     ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
     CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
   }
+  const uint32_t slot = s->stats_slot ^ 1u; /* the previous scan's record may not have been looked at yet */
   {
     ProfScope ps(c, "k6_icp_finish", 0.0);
-    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+    c->gn_host_out = &s->h_res[1 + slot];
+    c->gn_host_seq = s->res_seq;
+    hipError_t e = launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0);
+    c->gn_host_out = nullptr;
+    CK(e);
   }
-  const uint32_t slot = s->stats_slot ^ 1u; /* the previous scan's copy may not have been looked at yet */
-  CK(hipMemcpyAsync(&s->h_stats[slot], gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-  /* --- wait for the minimisation result only (poll: no blocking wake-up) --- */
-  for (;;) {
-    hipError_t q = hipEventQuery(c->ev_result);
-    if (q == hipSuccess) break;
-    if (q != hipErrorNotReady) CK(q);
-  }
-  resolve_stats(s, false); /* the previous scan's statistics copy precedes ev_result in the stream */
+  /* --- wait for the minimisation result only (poll on the record's sequence number) --- */
+  int r = wait_host_result(c, &s->h_res[0], s->res_seq);
+  if (r) return r;
+  resolve_stats(s, false); /* the previous scan's statistics launch precedes this result in the stream */
   s->stats_slot = slot;
+  *c->h_ds = s->h_res[0].ds;
   c->known_surfels = c->h_ds->n_surfels;
-  memcpy(increment, c->h_gn[0].Tk, sizeof(increment));
-  fill_stats(c->h_gn[0], &mst);
-  int r = check_overflow(c);
+  memcpy(increment, s->h_res[0].Tk, sizeof(increment));
+  fill_stats_host(s->h_res[0], &mst);
+  r = check_overflow(c);
   if (r) return r;
   s->stats_mst = mst;
+  s->stats_seq = s->res_seq;
   s->stats_pending = true;
 
   double inv_last[16], delta[16], posed[16];

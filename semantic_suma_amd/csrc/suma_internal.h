@@ -59,6 +59,19 @@ struct GnState {
   double Jtr[6];
 };
 
+/* What the host reads back after a minimisation of the scan pipeline.  The closing launch of the chain
+ * writes it straight into pinned host memory (seq last, behind a system-scope fence), so the result
+ * costs no copy commands in the stream: the re-rendering that follows the minimisation starts right
+ * behind the closing launch, and the host polls seq. */
+struct HostResult {
+  double Tk[16];
+  double F, F_inlier;
+  uint32_t valid, outlier, invalid, k, converged, iteration;
+  DevState ds;
+  uint32_t seq;
+  uint32_t pad;
+};
+
 struct MapConsts {
   float pixel_size, log_prior, log_unstable, p_unstable;
   float radconf_angle_thresh, update_angle_thresh;
@@ -99,6 +112,8 @@ struct suma_ctx {
   GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
   int64_t* gn_partial; /* 2 x SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
   uint32_t gn_launch;  /* launches since the last gn_init */
+  HostResult* gn_host_out; /* if set: the closing launch being enqueued reports to this pinned host record ... */
+  uint32_t gn_host_seq;    /* ... and stamps it with this sequence number */
   int gn_emit_pose;        /* the closing launch of the chain being enqueued writes pose_block */
   double gn_pose_base[16];
   float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
@@ -178,7 +193,8 @@ struct suma_pipeline {
   uint32_t track_loss;
   /* the statistics pass of updatePose (SurfelMapping.cpp:411-423) is read back lazily: its copy is
    * enqueued, and resolved at the next synchronisation point instead of stalling the scan */
-  GnState* h_stats; /* pinned, 2 entries: the copy of scan t may still be in flight when scan t+1 enqueues its own */
+  HostResult* h_res; /* pinned: [0] minimisation result, [1..2] statistics pass (alternating) */
+  uint32_t res_seq, stats_seq;
   bool stats_pending;
   uint32_t stats_slot;
   suma_icp_stats stats_mst;
