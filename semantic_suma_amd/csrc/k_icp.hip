@@ -223,13 +223,21 @@ __global__ void k_gn_init(GnState* gn, const double* T0s, double* history, uint3
   }
   gn_reset(g, t, iteration0);
 }
+#define ICP_RECORDS 8 /* accumulator records per hypothesis (power of two) */
 struct IterArgs {
   IcpArgs a;
   const GnState* gin;  /* state written by the previous launch */
   GnState* gout;       /* state this launch writes */
-  const long long* pin; /* partials of the previous launch's pixel phase */
+  /* Block sums of a pixel phase are ADDED (memory-side 64-bit atomics; the sums are exact integers, so
+   * the order is immaterial) into ICP_RECORDS accumulator records per hypothesis -- the next launch
+   * totals 8 records instead of one per block.  Three buffers rotate: this launch reads pin (written by
+   * the previous launch), adds into pout (zeroed by the previous launch) and zeroes pzero (read by the
+   * previous launch) for the next one. */
+  const long long* pin;
   long long* pout;
-  uint32_t nblocks;    /* blocks of a pixel phase = partial records per hypothesis */
+  long long* pzero;
+  uint32_t zero_hyp; /* hypotheses whose records in pzero may be non-zero */
+  uint32_t nblocks;    /* blocks of a pixel phase */
   uint32_t max_iter;
   double epsilon, delta_thr;
   int eval_only; /* Frame2Model::jacobianProducts only: no solve, no pose update */
@@ -271,6 +279,10 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   __shared__ double s_pose[16];
   __shared__ uint32_t s_flag[4]; /* done, iteration */
 
+  if (blockIdx.x == 0 && threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) /* for the next launch */
+    for (uint32_t h = blockIdx.y; h < g.zero_hyp; h += gridDim.y)
+      g.pzero[(size_t)h * ICP_RECORDS * SUMA_ACC_WORDS + threadIdx.x] = 0;
+
   /* wave-uniform state (scalar loads), or the start state of a fresh chain */
   const uint32_t done_in = g.init ? 0u : gin->done, pending = g.init ? 0u : gin->pending;
   uint32_t iteration = g.init ? g.iteration0 : gin->iteration;
@@ -292,29 +304,14 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   float prefetch_sink = 0.0f;
   uint32_t done = done_in;
   if (pending) {
-    /* ---- total of the previous launch's partials: one batch of independent loads per lane ---- */
-    const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * g.nblocks * SUMA_ACC_WORDS;
-    {
-      const int word = threadIdx.x & 31, grp = threadIdx.x >> 5;
-      constexpr int G = ICP_THREADS / 32;
-      long long s = 0;
-      for (uint32_t b0 = grp; b0 < g.nblocks; b0 += G * 16) {
-        long long v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          uint32_t b = b0 + G * u;
-          v[u] = (b < g.nblocks) ? pin[(size_t)b * SUMA_ACC_WORDS + word] : 0ll;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += v[u];
-      }
-      s_tot[grp][word] = s;
-    }
+    /* ---- total of the previous launch's accumulator records: one load per lane ---- */
+    const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * ICP_RECORDS * SUMA_ACC_WORDS;
+    if (threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) s_tot[threadIdx.x >> 5][threadIdx.x & 31] = pin[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < SUMA_ACC_WORDS) { /* 32 lanes fold the 16 groups; lane 0 then reads 32 words */
+    if (threadIdx.x < SUMA_ACC_WORDS) { /* 32 lanes fold the records; lane 0 then reads 32 words */
       long long s = 0;
 #pragma unroll
-      for (int q = 0; q < ICP_THREADS / 32; ++q) s += s_tot[q][threadIdx.x];
+      for (int q = 0; q < ICP_RECORDS; ++q) s += s_tot[q][threadIdx.x];
       s_wave[0][threadIdx.x] = s;
     }
     __syncthreads();
@@ -603,8 +600,9 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     long long s = 0;
 #pragma unroll
     for (int w = 0; w < ICP_THREADS / 64; ++w) s += s_wave[w][threadIdx.x];
-    long long* pout = g.pout + (size_t)blockIdx.y * g.nblocks * SUMA_ACC_WORDS;
-    pout[(size_t)blockIdx.x * SUMA_ACC_WORDS + threadIdx.x] = s;
+    unsigned long long* pout = reinterpret_cast<unsigned long long*>(g.pout) +
+                               ((size_t)blockIdx.y * ICP_RECORDS + (blockIdx.x & (ICP_RECORDS - 1))) * SUMA_ACC_WORDS;
+    atomicAdd(&pout[threadIdx.x], (unsigned long long)s);
   }
   if (prefetch_sink == 1.2345678e-30f && writer) gout->pad[0] = 1; /* keeps the prefetch loads alive */
   if (writer) gout->pending = 1;
@@ -641,8 +639,8 @@ static IcpArgs make_args(suma_ctx* c) {
 
 /* state / partial buffers alternate with the launch parity c->gn_launch */
 static GnState* gn_buf(suma_ctx* c, uint32_t parity) { return c->gn + (size_t)(parity & 1u) * SUMA_MAX_HYP; }
-static long long* part_buf(suma_ctx* c, uint32_t parity) {
-  return (long long*)c->gn_partial + (size_t)(parity & 1u) * SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS;
+static long long* part_buf(suma_ctx* c, uint32_t launch) {
+  return (long long*)c->gn_partial + (size_t)(launch % 3u) * SUMA_MAX_HYP * ICP_RECORDS * SUMA_ACC_WORDS;
 }
 
 hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0) {
@@ -669,8 +667,14 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.a = make_args(c);
   g.gin = gn_buf(c, c->gn_launch);
   g.gout = gn_buf(c, c->gn_launch + 1);
-  g.pin = part_buf(c, c->gn_launch);
-  g.pout = part_buf(c, c->gn_launch + 1);
+  /* the accumulator rotation runs across chains (gn_launch restarts with every chain, this does not) */
+  const uint32_t rot = c->gn_part_launch++;
+  g.pin = part_buf(c, rot);
+  g.pout = part_buf(c, rot + 1);
+  g.pzero = part_buf(c, rot + 2);
+  g.zero_hyp = c->gn_part_dirty[(rot + 2) % 3u];
+  c->gn_part_dirty[(rot + 2) % 3u] = 0;
+  if (pixel && c->gn_part_dirty[(rot + 1) % 3u] < n_hyp) c->gn_part_dirty[(rot + 1) % 3u] = n_hyp;
   g.nblocks = c->icp_blocks;
   g.max_iter = max_iter;
   g.epsilon = epsilon;

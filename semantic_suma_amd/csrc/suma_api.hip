@@ -280,6 +280,10 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->gn, 2 * SUMA_MAX_HYP * sizeof(GnState)));
     CK(hipMemsetAsync(c->gn, 0, 2 * SUMA_MAX_HYP * sizeof(GnState), c->stream));
     CK(hipMalloc((void**)&c->gn_partial, (size_t)2 * SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS * sizeof(int64_t)));
+    c->gn_part_launch = 0;
+    c->gn_part_dirty[0] = c->gn_part_dirty[1] = c->gn_part_dirty[2] = 0;
+    /* the rotating accumulator records of the Gauss-Newton chain start out zero (k_icp.hip, IterArgs) */
+    CK(hipMemset(c->gn_partial, 0, (size_t)2 * SUMA_MAX_HYP * c->icp_blocks * SUMA_ACC_WORDS * sizeof(int64_t)));
     c->gn_launch = 0;
     c->gn_history_cap = 1025;
     CK(hipMalloc((void**)&c->gn_history, (size_t)c->gn_history_cap * 16 * sizeof(double)));

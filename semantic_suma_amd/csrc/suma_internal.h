@@ -110,7 +110,9 @@ struct suma_ctx {
   /* ICP */
   const suma_frame *icp_current, *icp_model;
   GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
-  int64_t* gn_partial; /* 2 x SUMA_MAX_HYP x icp_blocks x SUMA_ACC_WORDS */
+  int64_t* gn_partial; /* 3 rotating sets of SUMA_MAX_HYP x ICP_RECORDS x SUMA_ACC_WORDS accumulators (k_icp.hip) */
+  uint32_t gn_part_launch;   /* rotation counter, never reset */
+  uint32_t gn_part_dirty[3]; /* hypotheses with possibly non-zero records, per set */
   uint32_t gn_launch;  /* launches since the last gn_init */
   HostResult* gn_host_out; /* if set: the closing launch being enqueued reports to this pinned host record ... */
   uint32_t gn_host_seq;    /* ... and stamps it with this sequence number */
