@@ -172,7 +172,13 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
   const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t blk0 = blockIdx.x * RENDER_THREADS; blk0 < S; blk0 += gridDim.x * RENDER_THREADS) {
+  /* Tiles are taken from the END of the surfel array first: the array is in creation order, so its tail holds
+   * the surfels around the sensor's recent positions -- the ones in view, with pixel tests to run -- and its
+   * head mostly surfels that leave after phase 1a.  Dispatching the expensive tiles first keeps the cheap
+   * ones for the kernel's tail. */
+  const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
+  for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
     const uint32_t i = blk0 + threadIdx.x;
     float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
     bool live = false;
