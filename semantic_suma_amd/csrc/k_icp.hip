@@ -127,6 +127,12 @@ __device__ __forceinline__ int word_of_lane(int lane) {
          ((lane >> 1) & 1);
 }
 
+__device__ __forceinline__ long long readlane_ll(long long v, int src) {
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), src);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 /* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64, fixed operation order */
 __device__ __forceinline__ void solve6(const double* A, const double* b, double* x) {
   double L[36], D[6], y[6];
@@ -259,6 +265,9 @@ struct IterArgs {
   HostResult* host_out;
   uint32_t host_seq;
   const DevState* ds;
+  /* eval-only pixel launch that reports by itself (last block), see the end of icp_iter_body */
+  HostResult* fused_report;
+  uint32_t* fused_counter;
 };
 
 /* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
@@ -604,6 +613,48 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
                                ((size_t)blockIdx.y * ICP_RECORDS + (blockIdx.x & (ICP_RECORDS - 1))) * SUMA_ACC_WORDS;
     atomicAdd(&pout[threadIdx.x], (unsigned long long)s);
   }
+  if (PIXEL && g.fused_report != nullptr) {
+    /* Objective-value-only pass (eval_only, one hypothesis) that closes itself: the block that finds every
+     * other block's sums already added totals the records and reports to the host, so the pass needs no
+     * consume-only launch behind it.  The 32 adding lanes sit in wave 0: the wait below completes all of
+     * them (memory-side atomics) before lane 0 takes its number. */
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* completion of the adds, without an L2 write-back */
+    if (threadIdx.x == 0)
+      s_flag[3] = (__hip_atomic_fetch_add(g.fused_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                   gridDim.x - 1u);
+    __syncthreads();
+    if (s_flag[3]) {
+      if (threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS)
+        s_tot[threadIdx.x >> 5][threadIdx.x & 31] =
+            __hip_atomic_load(g.pout + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if (threadIdx.x < SUMA_ACC_WORDS) {
+        long long s = 0;
+#pragma unroll
+        for (int q = 0; q < ICP_RECORDS; ++q) s += s_tot[q][threadIdx.x];
+        const long long n_valid = readlane_ll(s, 29), n_outlier = readlane_ll(s, 30), n_inlier = n_valid - n_outlier;
+        const long long n_invalid = readlane_ll(s, 31);
+        const int w = threadIdx.x;
+        if (w == 28) s -= n_inlier * MAGIC_BITS;
+        if (w == 27) s -= n_valid * MAGIC_BITS;
+        const double v = (double)s * (1.0 / SUMA_ACC_SCALE);
+        HostResult* __restrict__ h = g.fused_report;
+        if (w == 27) h->F = v;
+        if (w == 28) h->F_inlier = v;
+        if (w == 0) {
+          h->valid = (uint32_t)n_valid;
+          h->outlier = (uint32_t)n_outlier;
+          h->invalid = (uint32_t)n_invalid;
+          h->k = 0;
+          h->converged = 0;
+          h->iteration = iteration;
+          *g.fused_counter = 0; /* re-armed for the next pass (stream order) */
+        }
+        __threadfence_system();
+        if (w == 0) __hip_atomic_store(&h->seq, g.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
   if (prefetch_sink == 1.2345678e-30f && writer) gout->pad[0] = 1; /* keeps the prefetch loads alive */
   if (writer) gout->pending = 1;
 }
@@ -689,6 +740,8 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.host_out = pixel ? nullptr : c->gn_host_out;
   g.host_seq = c->gn_host_seq;
   g.ds = c->ds;
+  g.fused_report = (pixel && eval_only && n_hyp == 1) ? c->gn_fused_report : nullptr;
+  g.fused_counter = &c->ds->reserved0;
   g.init = c->gn_init_pending;
   g.iteration0 = c->gn_iteration0;
   for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];

@@ -293,6 +293,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipEventCreateWithFlags(&c->ev_result, hipEventDisableTiming));
     c->gn_emit_pose = 0;
     c->gn_host_out = nullptr;
+    c->gn_fused_report = nullptr;
     c->gn_host_seq = 0;
     /* submap cache arena */
     /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
@@ -1126,17 +1127,14 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;
   CK(launch_gn_init(c, I, 1, 0, 0));
-  {
-    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
-    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
-  }
   const uint32_t slot = s->stats_slot ^ 1u; /* the previous scan's record may not have been looked at yet */
   {
-    ProfScope ps(c, "k6_icp_finish", 0.0);
-    c->gn_host_out = &s->h_res[1 + slot];
+    /* one launch: the pass closes itself (last block totals and reports to the host record) */
+    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
+    c->gn_fused_report = &s->h_res[1 + slot];
     c->gn_host_seq = s->res_seq;
-    hipError_t e = launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0);
-    c->gn_host_out = nullptr;
+    hipError_t e = launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1);
+    c->gn_fused_report = nullptr;
     CK(e);
   }
   /* --- wait for the minimisation result only (poll on the record's sequence number) --- */

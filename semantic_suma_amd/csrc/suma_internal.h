@@ -32,7 +32,7 @@ struct DevState {
   uint32_t n_extracted;    /* K12: surfels written by the last extraction */
   uint32_t overflow;       /* bit 0: surfel capacity, bit 1: cache arena, bit 2: extract capacity, bit 3: compaction spin limit */
   uint32_t ticket;         /* dynamic tile id of the look-back compaction kernels */
-  uint32_t reserved0;
+  uint32_t reserved0;      /* blocks-done counter of a self-closing objective pass (k_icp.hip) */
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
   uint32_t pad[6];
 };
@@ -114,6 +114,7 @@ struct suma_ctx {
   uint32_t gn_part_launch;   /* rotation counter, never reset */
   uint32_t gn_part_dirty[3]; /* hypotheses with possibly non-zero records, per set */
   uint32_t gn_launch;  /* launches since the last gn_init */
+  HostResult* gn_fused_report; /* if set: the next eval-only pixel launch closes itself and reports here (gn_host_seq) */
   HostResult* gn_host_out; /* if set: the closing launch being enqueued reports to this pinned host record ... */
   uint32_t gn_host_seq;    /* ... and stamps it with this sequence number */
   int gn_emit_pose;        /* the closing launch of the chain being enqueued writes pose_block */
