@@ -456,17 +456,25 @@ __device__ __forceinline__ bool k9_finish(const UpdArgs& a, uint32_t i, const Su
  *
  * The per-surfel work is a chain of dependent memory round trips (surfel -> pose entry -> measurement
  * record) with divergent arithmetic at the end, so the kernel is organised for latency, not bandwidth:
- *  - 512-thread blocks, TWO surfels per lane with the stages of both interleaved (twice the loads in
- *    flight per wave), 64 KB of LDS -> two blocks per CU that run out of phase: while one sits in its
- *    barrier / look-back wait the other computes;
+ *  - the three stages of a surfel are separate functions, so a lane can run K9_PER surfels with their
+ *    stages interleaved (K9_PER x the loads in flight per wave).  Measured: 2 x 512 threads and
+ *    1 x 1024 threads are equal at 1 M surfels; at 50 M surfels 16 waves per CU win (2.06 vs 1.73 TB/s),
+ *    hence K9_PER = 1;
  *  - a lane drops its updated record into LDS at its own (uncompacted) slot as soon as it is computed;
- *    the stable ranks follow from two ballots and a rank -> slot table, and the stream-out walks that
- *    table, writing a dense 16 B-per-lane stream instead of 64-byte-strided record stores;
+ *    the stable ranks follow from ballots and a rank -> slot table, and the stream-out walks that table,
+ *    writing a dense 16 B-per-lane stream instead of 64-byte-strided record stores;
+ *  - the records are double buffered in LDS (2 x 64 KB): a tile's output offset depends on every earlier
+ *    tile of the launch having published its count, so it is collected only after the NEXT tile has been
+ *    computed and published -- by then the words are almost always there (waiting right after the compute
+ *    exposes each block to the slowest of the ~256 tiles in flight ahead of it);
  *  - the barriers are LDS-only (no vmcnt drain): the fire-and-forget stores (integration mask, status
  *    words, the previous tile's stream-out) stay in flight across them. */
-#define K9_THREADS 512
+#ifndef K9_PER
+#define K9_PER 1 /* surfels per lane (see above) */
+#endif
+#define K9_THREADS (SUMA_TILE / K9_PER)
 #define K9_WAVES (K9_THREADS / 64)
-static_assert(SUMA_TILE == 2 * K9_THREADS, "K9 processes two surfels per lane");
+static_assert(SUMA_TILE % K9_PER == 0 && K9_THREADS <= 1024, "K9 tile split");
 
 __device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, uint32_t i) {
   Surfel4 r;
@@ -480,7 +488,7 @@ __device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, ui
 __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
   __shared__ float4 s_out[2][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
   __shared__ uint16_t s_slot[2][SUMA_TILE]; /* stable rank -> slot */
-  __shared__ uint32_t s_cnt_emit[2][K9_WAVES], s_cnt_keep[K9_WAVES];
+  __shared__ uint32_t s_cnt_emit[K9_PER][K9_WAVES], s_cnt_keep[K9_WAVES];
   __shared__ uint32_t s_tile, s_prefix;
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
@@ -498,64 +506,66 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
     const uint32_t tile = s_tile;
     uint32_t total = 0;
     if (tile < ntiles) {
-      const uint32_t slot0 = threadIdx.x, slot1 = K9_THREADS + threadIdx.x;
-      const uint32_t i0 = tile * SUMA_TILE + slot0, i1 = tile * SUMA_TILE + slot1;
-      const bool live0 = i0 < S, live1 = i1 < S;
-      /* out-of-range lanes read surfel 0 (S > 0 here) and are masked at the end */
-      const Surfel4 in0 = load_surfel(sf, live0 ? i0 : 0u), in1 = load_surfel(sf, live1 ? i1 : 0u);
-      const K9Pre p0 = k9_prepare(a, in0), p1 = k9_prepare(a, in1);
-      const K9Rec g0 = k9_gather(a, p0), g1 = k9_gather(a, p1);
-      bool keep0, keep1, emit0, emit1;
-      {
+      /* lane t handles slots t, K9_THREADS + t, ...: slot order = surfel order = stable order */
+      uint32_t idx[K9_PER];
+      bool live[K9_PER], emit[K9_PER];
+      Surfel4 in[K9_PER];
+      K9Pre pre[K9_PER];
+      K9Rec rec[K9_PER];
+#pragma unroll
+      for (int u = 0; u < K9_PER; ++u) {
+        idx[u] = tile * SUMA_TILE + (uint32_t)u * K9_THREADS + threadIdx.x;
+        live[u] = idx[u] < S;
+        in[u] = load_surfel(sf, live[u] ? idx[u] : 0u); /* out-of-range lanes read surfel 0 (S > 0 here), masked below */
+      }
+#pragma unroll
+      for (int u = 0; u < K9_PER; ++u) pre[u] = k9_prepare(a, in[u]);
+#pragma unroll
+      for (int u = 0; u < K9_PER; ++u) rec[u] = k9_gather(a, pre[u]);
+      uint32_t kept = 0;
+      unsigned long long eb[K9_PER];
+#pragma unroll
+      for (int u = 0; u < K9_PER; ++u) {
         Surfel4 o;
         int32_t mark_pix;
-        keep0 = k9_finish(a, i0, in0, p0, g0, o, &mark_pix) && live0;
-        if (keep0 && mark_pix >= 0) a.integrated[mark_pix] = 1;
-        emit0 = keep0 && in_active_area(a, o);
-        s_out[buf][slot0][0] = o.a;
-        s_out[buf][slot0][1] = o.b;
-        s_out[buf][slot0][2] = o.c;
-        s_out[buf][slot0][3] = o.d;
+        const bool keep = k9_finish(a, idx[u], in[u], pre[u], rec[u], o, &mark_pix) && live[u];
+        if (keep && mark_pix >= 0) a.integrated[mark_pix] = 1;
+        emit[u] = keep && in_active_area(a, o);
+        const uint32_t slot = (uint32_t)u * K9_THREADS + threadIdx.x;
+        s_out[buf][slot][0] = o.a;
+        s_out[buf][slot][1] = o.b;
+        s_out[buf][slot][2] = o.c;
+        s_out[buf][slot][3] = o.d;
+        eb[u] = __ballot(emit[u]);
+        kept += __popcll(__ballot(keep));
       }
-      {
-        Surfel4 o;
-        int32_t mark_pix;
-        keep1 = k9_finish(a, i1, in1, p1, g1, o, &mark_pix) && live1;
-        if (keep1 && mark_pix >= 0) a.integrated[mark_pix] = 1;
-        emit1 = keep1 && in_active_area(a, o);
-        s_out[buf][slot1][0] = o.a;
-        s_out[buf][slot1][1] = o.b;
-        s_out[buf][slot1][2] = o.c;
-        s_out[buf][slot1][3] = o.d;
-      }
-      const unsigned long long eb0 = __ballot(emit0), eb1 = __ballot(emit1);
-      const uint32_t kept = __popcll(__ballot(keep0)) + __popcll(__ballot(keep1));
       if (lane == 0) {
         s_cnt_keep[wave] = kept; /* S' statistics (parity with the reference's TF count) */
-        s_cnt_emit[0][wave] = __popcll(eb0);
-        s_cnt_emit[1][wave] = __popcll(eb1);
+#pragma unroll
+        for (int u = 0; u < K9_PER; ++u) s_cnt_emit[u][wave] = __popcll(eb[u]);
       }
       lds_barrier();
-      uint32_t off0 = 0, off1 = 0, tot0 = 0, tot1 = 0, kc = 0;
+      uint32_t kc = 0, base = 0;
+      const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
-      for (int w = 0; w < K9_WAVES; ++w) {
-        const uint32_t c0 = s_cnt_emit[0][w], c1 = s_cnt_emit[1][w];
-        if (w < wave) {
-          off0 += c0;
-          off1 += c1;
+      for (int u = 0; u < K9_PER; ++u) {
+        uint32_t off = 0, tot = 0;
+#pragma unroll
+        for (int w = 0; w < K9_WAVES; ++w) {
+          const uint32_t cnt = s_cnt_emit[u][w];
+          if (w < wave) off += cnt;
+          tot += cnt;
         }
-        tot0 += c0;
-        tot1 += c1;
-        kc += s_cnt_keep[w];
+        if (emit[u]) s_slot[buf][base + off + __popcll(eb[u] & below)] = (uint16_t)((uint32_t)u * K9_THREADS + threadIdx.x);
+        base += tot;
       }
-      total = tot0 + tot1;
+#pragma unroll
+      for (int w = 0; w < K9_WAVES; ++w) kc += s_cnt_keep[w];
+      total = base;
       if (threadIdx.x == 0) {
         keep_count += kc;
         lookback_publish(a.status, a.group, tile, total, a.epoch);
       }
-      const unsigned long long below = (1ull << lane) - 1ull;
-      if (emit0) s_slot[buf][off0 + __popcll(eb0 & below)] = (uint16_t)slot0;
-      if (emit1) s_slot[buf][tot0 + off1 + __popcll(eb1 & below)] = (uint16_t)slot1;
     }
     /* the PREVIOUS tile's offset: every tile before it was drawn before it and is published without
      * any wait in between, and this block has published everything it holds -- no circular wait; by
