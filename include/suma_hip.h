@@ -133,6 +133,8 @@ int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
 int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
 int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);
 uint32_t suma_pipeline_timestamp(const suma_pipeline* s);
+/* number of scans on which the frame-to-frame fallback minimisation ran (trackLoss_, SurfelMapping.cpp:441) */
+uint32_t suma_pipeline_track_loss(const suma_pipeline* s);
 /* which: 0 current data frame, 1 last model frame, 2 current model frame */
 suma_frame* suma_pipeline_frame(suma_pipeline* s, int which);
 

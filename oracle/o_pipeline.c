@@ -111,6 +111,7 @@ void ora_pipeline_last_increment(const ora_pipeline* s, double inc[16]) {
   memcpy(inc, s->last_increment, 16 * sizeof(double));
 }
 void ora_pipeline_last_stats(const ora_pipeline* s, suma_icp_stats* st) { *st = s->stats; }
+uint32_t ora_pipeline_track_loss(const ora_pipeline* s) { return s->track_loss; } /* trackLoss_, SurfelMapping.cpp:441 */
 ora_frame* ora_pipeline_frame(ora_pipeline* s, int which) {
   return which == 0 ? s->current_frame : (which == 1 ? s->last_model : s->current_model);
 }

@@ -87,6 +87,8 @@ def lib(variant: str = ""):
     L.ora_pipeline_pose.argtypes = [vp, vp]
     L.ora_pipeline_last_increment.argtypes = [vp, vp]
     L.ora_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
+    L.ora_pipeline_track_loss.restype = C.c_uint32
+    L.ora_pipeline_track_loss.argtypes = [vp]
     L.ora_pipeline_frame.restype = vp
     L.ora_pipeline_frame.argtypes = [vp, C.c_int]
     L.ora_se3_exp.argtypes = [vp, vp]
@@ -310,6 +312,10 @@ class OraclePipeline:
         st = IcpStats()
         self.L.ora_pipeline_last_stats(self.h, C.byref(st))
         return st
+
+    def track_loss(self) -> int:
+        """scans on which the frame-to-frame fallback ran (trackLoss_, SurfelMapping.cpp:441)"""
+        return int(self.L.ora_pipeline_track_loss(self.h))
 
     def frame(self, which) -> OracleFrame:
         p = self.params

@@ -87,6 +87,7 @@ void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const
 void ora_pipeline_pose(const ora_pipeline* s, double pose[16]);
 void ora_pipeline_last_increment(const ora_pipeline* s, double inc[16]);
 void ora_pipeline_last_stats(const ora_pipeline* s, suma_icp_stats* st);
+uint32_t ora_pipeline_track_loss(const ora_pipeline* s);
 ora_frame* ora_pipeline_frame(ora_pipeline* s, int which); /* 0 current data, 1 last model, 2 current model */
 
 /* host math exposed for tests: SE3::exp (lie_algebra.cpp:4-34), 6x6 LDLT solve */

@@ -114,6 +114,8 @@ def lib():
     L.suma_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_pipeline_timestamp.restype = u32
     L.suma_pipeline_timestamp.argtypes = [vp]
+    L.suma_pipeline_track_loss.restype = u32
+    L.suma_pipeline_track_loss.argtypes = [vp]
     L.suma_pipeline_frame.restype = vp
     L.suma_pipeline_frame.argtypes = [vp, C.c_int]
     L.suma_device_alloc.argtypes = [vp, C.c_uint64, pp]
@@ -526,6 +528,10 @@ class SurfelMapping:
 
     def timestamp(self) -> int:
         return self.L.suma_pipeline_timestamp(self.h)
+
+    def trackLoss(self) -> int:
+        """scans on which the frame-to-frame fallback ran (trackLoss_, SurfelMapping.cpp:441)"""
+        return self.L.suma_pipeline_track_loss(self.h)
 
     def frame(self, which: int) -> Frame:
         """0 current data frame, 1 last model frame, 2 current model frame"""

@@ -1019,6 +1019,7 @@ extern "C" int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* 
   return SUMA_OK;
 }
 extern "C" uint32_t suma_pipeline_timestamp(const suma_pipeline* s) { return s ? s->timestamp : 0; }
+extern "C" uint32_t suma_pipeline_track_loss(const suma_pipeline* s) { return s ? s->track_loss : 0; }
 extern "C" suma_frame* suma_pipeline_frame(suma_pipeline* s, int which) {
   if (!s) return nullptr;
   return which == 0 ? s->current_frame : (which == 1 ? s->last_model : s->current_model);

@@ -309,6 +309,25 @@ def test_pipeline_process_scan(hip, oracle_lib, width, n_scans):
     assert t < 0.5, f"drift {t} m after {n_scans} scans"
 
 
+def test_pipeline_fallback_icp(hip, oracle_lib):
+    """A jump in the motion (two scans skipped) trips the frame-to-frame fallback minimisation
+    (SurfelMapping.cpp:434-449): same decision, same poses, same maps as the oracle."""
+    p = params_with_size(900)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for n, k in enumerate([0, 1, 2, 3, 6, 7]):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=10)
+        op.process_scan(pts, lab, prob, fixed_iterations=10)
+        assert hp.trackLoss() == op.track_loss(), f"scan {n}: fallback decision"
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {n}: pose bits"
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"scan {n} stats"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {n} surfels"
+        for w in (0, 1, 2):
+            frames_equal(hp.frame(w), op.frame(w), f"scan {n} frame {w}")
+    assert op.track_loss() >= 1, "the sequence was meant to trip the fallback"
+
+
 def test_pipeline_convergence_mode(hip, oracle_lib):
     """default.xml stopping tests (no fixed iteration count), no semantics: BASELINE config 1 style"""
     p = params_with_size(900, max_iterations=10)
