@@ -153,6 +153,36 @@ __device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
  * fire-and-forget stores into stalls.  Use where the data exchanged across the barrier lives in LDS. */
 SDEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+/* K8 for one measurement pixel (init_radiusConf.vert): radius / validity, cleared integration mark, and
+ * everything K9 gathers for the pixel packed into ONE 64-byte line (vertex, normal, label, label probability,
+ * radius) -- a surfel update then costs one random line instead of four.  Depends on the frame only, not on
+ * the pose: besides k8_radius, the pipeline's statistics pass (which streams the same three maps anyway)
+ * runs it. */
+struct K8Out {
+  float4* radius_conf;
+  uint8_t* integrated;
+  float4* pixrec;
+  float pixel_size, angle_thresh, min_radius, max_radius;
+};
+SDEV void k8_pixel(const K8Out& o, uint32_t pix, float4 v, float4 n, float4 sem) {
+  v3 vv = xyz(v), nn = xyz(n);
+  float d = len3(vv);
+  v3 view_dir = divs3(neg3(vv), d);
+  float angle = dot3(nn, view_dir);
+  float valid = 0.0f, radius = 0.0f;
+  if (v.w > 0.5f && n.w > 0.5f && angle > o.angle_thresh) {
+    valid = 1.0f;
+    radius = ((1.41f * d) * o.pixel_size) / fclamp(dot3(nn, divs3(neg3(vv), d)), 0.5f, 1.0f);
+    radius = fmin_(fmax_(radius, o.min_radius), o.max_radius);
+  }
+  o.radius_conf[pix] = f4(radius, 0.0f, 0.0f, valid); /* quirk B-3: the confidence channel stays 0 */
+  o.integrated[pix] = 0;
+  float4* r = o.pixrec + 4 * (size_t)pix;
+  r[0] = v;
+  r[1] = n;
+  r[2] = f4(sem.x, sem.w, radius, 0.0f);
+}
+
 #define SUMA_EMPTY_KEY (~0ull)
 
 /* Depth-tested write into a 64-bit z-buffer (key = depth24 << 32 | id, smaller wins).  A pixel that many

@@ -41,6 +41,11 @@ struct IcpArgs {
   float angle_thresh, distance_thresh, factor;
   int32_t weight_function, bilinear;
   uint32_t P;
+  /* statistics pass of the scan pipeline only: K8's per-pixel work for the frame that is being streamed
+   * anyway (dev_math.h, k8_pixel) and the per-update counter resets ride along */
+  int k8_enabled;
+  K8Out k8;
+  DevState* k8_ds;
 };
 
 __device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map, int32_t w, int32_t h, float x,
@@ -517,6 +522,15 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       nd4 = a.Nd[pix];
       sd4 = a.Sd[pix];
     }
+    if (a.k8_enabled) { /* launch-uniform */
+      k8_pixel(a.k8, pix, vd4, nd4, sd4);
+      if (pix == 0) {
+        a.k8_ds->n_updated = 0;
+        a.k8_ds->n_data = 0;
+        a.k8_ds->n_kept_updated = 0;
+        a.k8_ds->n_kept_data = 0;
+      }
+    }
     float e_d = vd4.w + nd4.w;
     bool pair = false;
     float4 vm4, nm4, sm4;
@@ -682,6 +696,9 @@ static IcpArgs make_args(suma_ctx* c) {
   a.angle_thresh = (float)cos((double)c->p.icp_max_angle * M_PI / 180.0);
   a.distance_thresh = c->p.icp_max_distance;
   a.factor = c->p.factor;
+  a.k8_enabled = 0;
+  a.k8 = launch_k8_out(c);
+  a.k8_ds = c->ds;
   a.weight_function = c->p.weight_function;
   a.bilinear = c->p.bilinear_sampling;
   a.P = (uint32_t)a.W * (uint32_t)a.H;
@@ -716,6 +733,7 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
                                 int eval_only, int with_history, int pixel) {
   IterArgs g;
   g.a = make_args(c);
+  g.a.k8_enabled = (pixel && eval_only && n_hyp == 1 && c->gn_fuse_k8) ? 1 : 0;
   g.gin = gn_buf(c, c->gn_launch);
   g.gout = gn_buf(c, c->gn_launch + 1);
   /* the accumulator rotation runs across chains (gn_launch restarts with every chain, this does not) */

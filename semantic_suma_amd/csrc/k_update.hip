@@ -139,45 +139,32 @@ __device__ __forceinline__ void finalise_tickets(DevState* ds, unsigned long lon
 /* ---------------------------------------------------------------------------------------------
  * K8 + clear of the integration mask
  * ------------------------------------------------------------------------------------------- */
+/* per-update counters + SurfelMap.cpp:494-495: poses_[timestamp_] = pose */
+__device__ __forceinline__ void write_pose_entry(float* poses, float* poses_inv, uint32_t pose_idx, const m4& pose) {
+  float inv[16];
+  rigid_inverse_dev(pose.m, inv);
+  for (int i = 0; i < 16; ++i) {
+    poses[16 * (size_t)pose_idx + i] = pose.m[i];
+    poses_inv[16 * (size_t)pose_idx + i] = inv[i];
+  }
+}
 __global__ void __launch_bounds__(256)
-    k8_radius(const float4* __restrict__ V, const float4* __restrict__ N, float4* __restrict__ radius_conf,
-              uint8_t* __restrict__ integrated, uint32_t P, float pixel_size, float angle_thresh, float min_radius,
-              float max_radius, DevState* ds, float* poses, float* poses_inv, uint32_t pose_idx, m4 pose,
-              const float4* __restrict__ Sem, float4* __restrict__ pixrec) {
+    k8_radius(const float4* __restrict__ V, const float4* __restrict__ N, K8Out o, uint32_t P, DevState* ds,
+              float* poses, float* poses_inv, uint32_t pose_idx, m4 pose, const float4* __restrict__ Sem) {
   uint32_t pix = blockIdx.x * blockDim.x + threadIdx.x;
   if (pix >= P) return;
-  if (pix == 0) { /* per-update counters + SurfelMap.cpp:494-495: poses_[timestamp_] = pose */
+  if (pix == 0) {
     ds->n_updated = 0;
     ds->n_data = 0;
     ds->n_kept_updated = 0;
     ds->n_kept_data = 0;
-    float inv[16];
-    rigid_inverse_dev(pose.m, inv);
-    for (int i = 0; i < 16; ++i) {
-      poses[16 * (size_t)pose_idx + i] = pose.m[i];
-      poses_inv[16 * (size_t)pose_idx + i] = inv[i];
-    }
+    write_pose_entry(poses, poses_inv, pose_idx, pose);
   }
-  float4 v = V[pix], n = N[pix];
-  v3 vv = xyz(v), nn = xyz(n);
-  float d = len3(vv);
-  v3 view_dir = divs3(neg3(vv), d);
-  float angle = dot3(nn, view_dir);
-  float valid = 0.0f, radius = 0.0f;
-  if (v.w > 0.5f && n.w > 0.5f && angle > angle_thresh) {
-    valid = 1.0f;
-    radius = ((1.41f * d) * pixel_size) / fclamp(dot3(nn, divs3(neg3(vv), d)), 0.5f, 1.0f);
-    radius = fmin_(fmax_(radius, min_radius), max_radius);
-  }
-  radius_conf[pix] = f4(radius, 0.0f, 0.0f, valid); /* quirk B-3: the confidence channel stays 0 */
-  integrated[pix] = 0;
-  /* everything K9 gathers for a measurement pixel, packed into ONE 64-byte line (vertex, normal,
-   * label, label probability, radius): a surfel update then costs one random line instead of four */
-  const float4 sem = Sem[pix];
-  float4* r = pixrec + 4 * (size_t)pix;
-  r[0] = v;
-  r[1] = n;
-  r[2] = f4(sem.x, sem.w, radius, 0.0f);
+  k8_pixel(o, pix, V[pix], N[pix], Sem[pix]);
+}
+/* the pose-table part alone, for updates whose per-pixel K8 work rode on the statistics pass */
+__global__ void k8_pose_only(float* poses, float* poses_inv, uint32_t pose_idx, m4 pose) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) write_pose_entry(poses, poses_inv, pose_idx, pose);
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -210,6 +197,11 @@ struct UpdArgs {
       update_always;
   /* K11 */
   float cx, cy, extent;
+  /* K9 also records poses_[timestamp_] when K8 did not run as a kernel of its own */
+  float* poses_w;
+  float* poses_inv_w;
+  uint32_t pose_idx;
+  int write_pose;
 };
 
 __device__ __forceinline__ void load_pose(const float* __restrict__ table, int32_t idx, float* M) {
@@ -496,6 +488,7 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
   float4* __restrict__ dst4 = reinterpret_cast<float4*>(a.out);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   uint32_t keep_count = 0; /* thread 0: survivors before the area filter (S') */
+  if (a.write_pose && blockIdx.x == 0 && threadIdx.x == 0) write_pose_entry(a.poses_w, a.poses_inv_w, a.pose_idx, a.pose);
   /* the tile whose records wait in LDS for their output offset */
   uint32_t prev_tile = 0xffffffffu, prev_total = 0, buf = 0;
   for (;;) {
@@ -719,6 +712,18 @@ static uint32_t stream_grid(suma_ctx* c, uint64_t items) {
   return (uint32_t)blocks;
 }
 
+K8Out launch_k8_out(suma_ctx* c) {
+  K8Out o;
+  o.radius_conf = c->radius_conf;
+  o.integrated = c->integrated;
+  o.pixrec = c->pixrec;
+  o.pixel_size = c->mc.pixel_size;
+  o.angle_thresh = c->mc.radconf_angle_thresh;
+  o.min_radius = c->p.min_radius;
+  o.max_radius = c->p.max_radius;
+  return o;
+}
+
 /* K7..K11 of SurfelMap::update for the current map (c->surfels[c->cur]); the result lands in the
  * other buffer, which the caller makes current. */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
@@ -732,6 +737,8 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.ds = c->ds;
   a.poses = c->poses;
   a.poses_inv = c->poses_inv;
+  a.poses_w = c->poses;
+  a.poses_inv_w = c->poses_inv;
   a.zbuf = c->zbuf_data;
   a.status = c->tile_status;
   a.group_words = c->group_words;
@@ -769,12 +776,19 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.extent = extent;
   hipStream_t st = c->stream;
   const uint32_t gridS = stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
-  {
+  a.pose_idx = c->timestamp;
+  a.write_pose = 0;
+  if (c->k8_fused_frame == f && c->k8_fused_stamp == c->timestamp && c->k8_fused_params == c->params_version) {
+    /* the per-pixel K8 products and the counter resets were produced by the statistics pass that streamed
+     * this frame (suma_api.hip, update_pose); what is left is the pose-table entry, which K9's first
+     * thread writes (nothing in K9 reads the entry of the current stamp) */
+    a.write_pose = 1;
+  } else {
     ProfScope ps(c, "k8_radius", 48.0 * P);
-    k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, c->radius_conf, c->integrated, P, c->mc.pixel_size,
-                                                c->mc.radconf_angle_thresh, c->p.min_radius, c->p.max_radius, c->ds, c->poses,
-                                                c->poses_inv, c->timestamp, a.pose, a.Sem, c->pixrec);
+    k8_radius<<<(P + 255) / 256, 256, 0, st>>>(a.V, a.N, launch_k8_out(c), P, c->ds, c->poses, c->poses_inv, c->timestamp,
+                                                a.pose, a.Sem);
   }
+  c->k8_fused_frame = nullptr;
   if (!k7_done) { /* otherwise the splat was fused into the post-ICP render pass (same pose, same map) */
     ProfScope ps(c, "k7_indexmap", 64.0 * S + 8.0 * P);
     k7_indexmap<<<gridS, 256, 0, st>>>(a);

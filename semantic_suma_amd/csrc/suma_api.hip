@@ -294,6 +294,8 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     c->gn_emit_pose = 0;
     c->gn_host_out = nullptr;
     c->gn_fused_report = nullptr;
+    c->gn_fuse_k8 = 0;
+    c->k8_fused_frame = nullptr;
     c->gn_host_seq = 0;
     /* submap cache arena */
     /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
@@ -435,6 +437,7 @@ extern "C" int suma_preprocess_device(suma_ctx* c, const suma_float4* d_points, 
   if (!c || !out || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
   if (out->width != c->p.data_width || out->height != c->p.data_height)
     return fail(c, SUMA_ERR_INVALID, "suma_preprocess: frame size differs from data_width x data_height");
+  if (c->k8_fused_frame == out) c->k8_fused_frame = nullptr; /* the frame's maps are about to change */
   CK(launch_preprocess(c, (const float4*)d_points, d_labels, d_probs, n, timestamp, out));
   return SUMA_OK;
 }
@@ -1134,9 +1137,16 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
     ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
     c->gn_fused_report = &s->h_res[1 + slot];
     c->gn_host_seq = s->res_seq;
+    /* this launch streams the three maps of the current frame: K8's per-pixel work for the update that
+     * follows (pose independent) and the per-update counter resets ride along -- no k8_radius launch */
+    c->gn_fuse_k8 = 1;
     hipError_t e = launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1);
+    c->gn_fuse_k8 = 0;
     c->gn_fused_report = nullptr;
     CK(e);
+    c->k8_fused_frame = s->current_frame;
+    c->k8_fused_stamp = c->timestamp;
+    c->k8_fused_params = c->params_version;
   }
   /* --- wait for the minimisation result only (poll on the record's sequence number) --- */
   int r = wait_host_result(c, &s->h_res[0], s->res_seq);

@@ -114,6 +114,11 @@ struct suma_ctx {
   uint32_t gn_part_launch;   /* rotation counter, never reset */
   uint32_t gn_part_dirty[3]; /* hypotheses with possibly non-zero records, per set */
   uint32_t gn_launch;  /* launches since the last gn_init */
+  /* per-pixel K8 products already written for (frame, stamp) by the statistics pass, see launch_map_update */
+  const suma_frame* k8_fused_frame;
+  uint32_t k8_fused_stamp;
+  uint64_t k8_fused_params;
+  int gn_fuse_k8; /* the next eval-only pixel launch also runs K8's per-pixel work and the counter resets */
   HostResult* gn_fused_report; /* if set: the next eval-only pixel launch closes itself and reports here (gn_host_seq) */
   HostResult* gn_host_out; /* if set: the closing launch being enqueued reports to this pinned host record ... */
   uint32_t gn_host_seq;    /* ... and stamps it with this sequence number */
@@ -245,6 +250,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
                              float cy, float extent, int k7_done);
 hipError_t launch_clear_index_zbuf(suma_ctx* c);
+K8Out launch_k8_out(suma_ctx* c);
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);
 hipError_t launch_fill_identity_poses(suma_ctx* c);
 hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent);
