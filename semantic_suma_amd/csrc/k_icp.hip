@@ -177,10 +177,12 @@ __device__ __forceinline__ void se3_exp(const double* x, double* T) {
     _Pragma("unroll") for (int r = 0; r < 3; ++r)
       _Pragma("unroll") for (int cc = 0; cc < 3; ++cc)
         K2[3 * r + cc] = (K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc]) + K[3 * r + 2] * K[6 + cc];
-    double alpha = sdm_sin_d(theta) / theta;
-    double beta = (1 - sdm_cos_d(theta)) / (theta * theta);
-    double gamma = (1.0 - sdm_cos_d(theta)) / (theta * theta);
-    double delta = (theta - sdm_sin_d(theta)) / (theta * theta * theta);
+    /* lie_algebra.cpp evaluates sin / cos twice each; same arguments, same values */
+    const double st = sdm_sin_d(theta), ct = sdm_cos_d(theta);
+    double alpha = st / theta;
+    double beta = (1 - ct) / (theta * theta);
+    double gamma = beta; /* (1.0 - cos(theta)) / (theta * theta) */
+    double delta = (theta - st) / (theta * theta * theta);
     _Pragma("unroll") for (int r = 0; r < 3; ++r) {
       double t = 0.0;
       _Pragma("unroll") for (int cc = 0; cc < 3; ++cc) {
