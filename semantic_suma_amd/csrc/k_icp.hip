@@ -138,31 +138,52 @@ __device__ __forceinline__ long long readlane_ll(long long v, int src) {
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
-/* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64, fixed operation order */
-__device__ __forceinline__ void solve6(const double* A, const double* b, double* x) {
-  double L[36], D[6], y[6];
-  _Pragma("unroll") for (int i = 0; i < 36; ++i) L[i] = 0.0;
-  _Pragma("unroll") for (int j = 0; j < 6; ++j) {
-    double d = A[6 * j + j];
-    _Pragma("unroll") for (int k = 0; k < j; ++k) d -= (L[6 * k + j] * L[6 * k + j]) * D[k];
-    D[j] = d;
-    L[6 * j + j] = 1.0;
-    _Pragma("unroll") for (int i = j + 1; i < 6; ++i) {
-      double s = A[6 * j + i];
-      _Pragma("unroll") for (int k = 0; k < j; ++k) s -= (L[6 * k + i] * L[6 * k + j]) * D[k];
-      L[6 * j + i] = s / d;
-    }
+__device__ __forceinline__ double bcast_d(double v, int src) { /* value of lane `src`, wave-uniform */
+  const long long b = __double_as_longlong(v);
+  const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)b, src);
+  const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)b >> 32), src);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+/* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64 with the fixed operation order of
+ * the oracle (oracle/o_icp.c, ora_solve6), the six rows of L spread over lanes 0..5 of a wave (every lane of
+ * the wave runs this; lanes >= 6 shadow lane 5).  Each element goes through exactly the serial algorithm's
+ * operations, in the same order -- what changes is that the five quotients of a column (and the six of
+ * y / D) are formed side by side: a one-lane version spends two thirds of its instructions in 21 dependent
+ * fp64 divisions, this one issues 6 (fp64 instructions of the launch: 1025 -> 539).
+ * val = the 21 packed upper-triangle entries of JtJ followed by Jtr (LDS); x comes back wave-uniform. */
+__device__ __forceinline__ void solve6_wave(const double* val, int lane, double* x) {
+  const int li = lane < 6 ? lane : 5;
+  double Acol[6], Lrow[6], D[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int lo = li < j ? li : j, hi = li < j ? j : li;
+    Acol[j] = val[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)]; /* JtJ(li, j), symmetric */
+    Lrow[j] = 0.0;
   }
-  _Pragma("unroll") for (int i = 0; i < 6; ++i) {
-    double s = -b[i];
-    _Pragma("unroll") for (int k = 0; k < i; ++k) s -= L[6 * k + i] * y[k];
-    y[i] = s;
+  double Dmine = 1.0;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    double sacc = Acol[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) sacc -= (Lrow[k] * bcast_d(Lrow[k], j)) * D[k];
+    D[j] = bcast_d(sacc, j); /* on lane j the sum above is d_j: (L[k][j] * L[k][j]) * D[k] */
+    if (li == j) Dmine = sacc;
+    Lrow[j] = sacc / D[j]; /* rows li > j; 1 on lane j, unused elsewhere */
   }
-  _Pragma("unroll") for (int i = 0; i < 6; ++i) y[i] = y[i] / D[i];
-  _Pragma("unroll") for (int i = 5; i >= 0; --i) {
-    double s = y[i];
-    _Pragma("unroll") for (int k = i + 1; k < 6; ++k) s -= L[6 * i + k] * x[k];
-    x[i] = s;
+  double y = -val[21 + li];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double yk = bcast_d(y, k); /* final on lane k: it only ever subtracts terms k' < k */
+    if (li > k) y -= Lrow[k] * yk;
+  }
+  y = y / Dmine;
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+    double sacc = bcast_d(y, i);
+#pragma unroll
+    for (int k = i + 1; k < 6; ++k) sacc -= bcast_d(Lrow[i], k) * x[k]; /* L[i][k] lives in row k */
+    x[i] = sacc;
   }
 }
 
@@ -292,8 +313,8 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
 
   __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
   __shared__ long long s_tot[ICP_THREADS / 32][SUMA_ACC_WORDS];
-  __shared__ double s_pose[16];
-  __shared__ uint32_t s_flag[4]; /* done, iteration */
+  __shared__ double s_pose[16], s_E[16], s_val[SUMA_ACC_WORDS];
+  __shared__ uint32_t s_flag[4]; /* done, iteration, history slot, last-block flag */
 
   if (blockIdx.x == 0 && threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) /* for the next launch */
     for (uint32_t h = blockIdx.y; h < g.zero_hyp; h += gridDim.y)
@@ -305,6 +326,15 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   double Tk[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) Tk[i] = g.init ? g.T0.m[i] : gin->Tk[i];
+
+  /* lanes 0..15 form one element each of exp(delta) * pose_ at the end of the prologue: their column of the
+   * current pose (and their own element, for launches that do not move the pose) comes straight from HBM */
+  double tk_col[4] = {0.0, 0.0, 0.0, 0.0}, tk_self = 0.0;
+  if (threadIdx.x < 16 && pending) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tk_col[q] = gin->Tk[4 * (threadIdx.x >> 2) + q];
+    tk_self = gin->Tk[threadIdx.x];
+  }
 
   /* data-frame loads of this lane's first pixel do not depend on the pose: issue them now so that
    * their latency overlaps the prologue */
@@ -324,11 +354,18 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * ICP_RECORDS * SUMA_ACC_WORDS;
     if (threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) s_tot[threadIdx.x >> 5][threadIdx.x & 31] = pin[threadIdx.x];
     __syncthreads();
-    if (threadIdx.x < SUMA_ACC_WORDS) { /* 32 lanes fold the records; lane 0 then reads 32 words */
-      long long s = 0;
+    if (threadIdx.x < SUMA_ACC_WORDS) {
+      /* 32 lanes fold the records, remove the fixed-point bias and convert: word w of the totals and its
+       * value in double land in LDS */
+      long long sum = 0;
 #pragma unroll
-      for (int q = 0; q < ICP_RECORDS; ++q) s += s_tot[q][threadIdx.x];
-      s_wave[0][threadIdx.x] = s;
+      for (int q = 0; q < ICP_RECORDS; ++q) sum += s_tot[q][threadIdx.x];
+      const long long n_valid = readlane_ll(sum, 29), n_outlier = readlane_ll(sum, 30), n_inlier = n_valid - n_outlier;
+      const int w = threadIdx.x;
+      if (w < 27 || w == 28) sum -= n_inlier * MAGIC_BITS;
+      if (w == 27) sum -= n_valid * MAGIC_BITS;
+      s_wave[0][w] = sum;
+      s_val[w] = (double)sum * (1.0 / SUMA_ACC_SCALE);
     }
     __syncthreads();
     if (PIXEL && threadIdx.x >= 64 && want_px && pix0 < a.P && (vd4.w + nd4.w) > 1.5f) {
@@ -354,65 +391,52 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
                         (ps[4 * t00] + ps[4 * (t00 + a.Wm) + 4]);
       }
     }
-    if (threadIdx.x == 0) {
-      long long tot_acc[SUMA_ACC_WORDS];
-#pragma unroll
-      for (int w = 0; w < SUMA_ACC_WORDS; ++w) tot_acc[w] = s_wave[0][w];
-      const long long n_valid = tot_acc[29], n_outlier = tot_acc[30], n_inlier = n_valid - n_outlier;
-#pragma unroll
-      for (int w = 0; w < 27; ++w) tot_acc[w] -= n_inlier * MAGIC_BITS;
-      tot_acc[27] -= n_valid * MAGIC_BITS;
-      tot_acc[28] -= n_inlier * MAGIC_BITS;
-      const double inv = 1.0 / SUMA_ACC_SCALE;
-      double JtJ[36], Jtr[6];
-      {
-        int k = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-          for (int j = i; j < 6; ++j) {
-            double v = (double)tot_acc[k++] * inv;
-            JtJ[6 * j + i] = v;
-            JtJ[6 * i + j] = v;
-          }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) Jtr[i] = (double)tot_acc[21 + i] * inv;
-      }
-      const double err = (double)tot_acc[27] * inv;
+    if (threadIdx.x < 64) {
+      /* ---- LieGaussNewton::step on wave 0: every lane runs it on wave-uniform values (same cost as one
+       *      lane), the 6x6 solve spreads its rows over lanes 0..5, lane 0 writes ---- */
+      const int lane = threadIdx.x;
+      const double err = s_val[27];
       if (writer) {
         gout->F = err;
-        gout->F_inlier = (double)tot_acc[28] * inv;
-        gout->valid = (uint32_t)n_valid;
-        gout->outlier = (uint32_t)n_outlier;
-        gout->invalid = (uint32_t)tot_acc[31];
+        gout->F_inlier = s_val[28];
+        gout->valid = (uint32_t)s_wave[0][29];
+        gout->outlier = (uint32_t)s_wave[0][30];
+        gout->invalid = (uint32_t)s_wave[0][31];
         if (g.eval_only) { /* Objective::jacobianProducts outputs */
-          for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = tot_acc[w];
-          for (int i = 0; i < 36; ++i) gout->JtJ[i] = JtJ[i];
-          for (int i = 0; i < 6; ++i) gout->Jtr[i] = Jtr[i];
+          for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = s_wave[0][w];
+          int k = 0;
+          for (int i = 0; i < 6; ++i)
+            for (int j = i; j < 6; ++j) {
+              const double v = s_val[k++];
+              gout->JtJ[6 * j + i] = v;
+              gout->JtJ[6 * i + j] = v;
+            }
+          for (int i = 0; i < 6; ++i) gout->Jtr[i] = s_val[21 + i];
         }
       }
-      uint32_t k = gin->k, n_hist = gin->n_hist, converged = gin->converged;
+      uint32_t k = gin->k, n_hist = gin->n_hist, converged = gin->converged, hist_slot = 0xffffffffu;
       double last_error = gin->last_error;
       if (!g.eval_only) {
         double dx[6];
-        solve6(JtJ, Jtr, dx);
+        solve6_wave(s_val, lane, dx);
         int result = 1;
-        double linf = 0.0, maxc = Jtr[0];
+        double linf = 0.0, maxc = s_val[21];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
-          double ad = dx[i] < 0 ? -dx[i] : dx[i];
+          const double ad = dx[i] < 0 ? -dx[i] : dx[i], ji = s_val[21 + i];
           if (ad > linf) linf = ad;
-          if (Jtr[i] > maxc) maxc = Jtr[i];
+          if (ji > maxc) maxc = ji;
         }
         if (linf < g.delta_thr) result = 0;                                   /* LieGaussNewton.cpp:64 */
         if ((maxc < 0 ? -maxc : maxc) < g.epsilon) result = 0;                /* :65 (quirk B-4) */
         double de = err - last_error;
         if (err < last_error && (de < 0 ? -de : de) < g.epsilon) result = 0;  /* :66 */
-        double E[16], Tn[16];
+        double E[16];
         se3_exp(dx, E);
-        mul4d(E, Tk, Tn); /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46) */
+        if (lane == 0) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) Tk[i] = Tn[i];
+          for (int i = 0; i < 16; ++i) s_E[i] = E[i];
+        }
         iteration += 1;
         last_error = err;
         if (result == 0) {
@@ -420,24 +444,35 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
           done = 1;
         } else {
           k += 1;
-          if (writer && g.history != nullptr && blockIdx.y == 0 && n_hist < g.history_cap)
-            for (int i = 0; i < 16; ++i) g.history[16 * (size_t)n_hist + i] = Tn[i];
+          if (g.history != nullptr && blockIdx.y == 0 && n_hist < g.history_cap) hist_slot = n_hist;
           n_hist += 1;
           if (k >= g.max_iter) done = 1;
         }
       }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s_pose[i] = Tk[i];
-      s_flag[0] = done;
-      s_flag[1] = iteration;
+      if (lane == 0) {
+        s_flag[0] = done;
+        s_flag[1] = iteration;
+      }
       if (writer) {
-        for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
         gout->last_error = last_error;
         gout->iteration = iteration;
         gout->k = k;
         gout->n_hist = n_hist;
         gout->converged = converged;
         gout->done = done;
+      }
+      if (lane < 16) {
+        /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46): one element per
+         * lane, the expression of mul4d().  LDS traffic of one wave is in order: lane 0's s_E stores above
+         * are visible to these loads without a barrier. */
+        double t = tk_self;
+        if (!g.eval_only) {
+          const int r = lane & 3;
+          t = ((s_E[r] * tk_col[0] + s_E[4 + r] * tk_col[1]) + s_E[8 + r] * tk_col[2]) + s_E[12 + r] * tk_col[3];
+          if (blockIdx.x == 0 && hist_slot != 0xffffffffu) g.history[16 * (size_t)hist_slot + lane] = t;
+        }
+        s_pose[lane] = t;
+        if (blockIdx.x == 0) gout->Tk[lane] = t;
       }
     }
     __syncthreads();
