@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
 # kernel label of the HIP-event scopes -> kernel symbol in rocprofv3 traces
-SYMBOL = {"k6_icp_step": "k_icp_step", "k6_icp_finish": "k_icp_finish", "k4_render_surfels": "k_render",
+SYMBOL = {"k6_icp_step": "k_icp_step", "k6k8_stats_radius": "k_icp_step", "k6_icp_finish": "k_icp_finish", "k4_render_surfels": "k_render",
           "k4k7_render_indexmap": "k_render", "k9_update_surfels": "k9_update", "k10_generate_surfels": "k10_generate",
           "k12_extract_submap": "k12_extract", "k7_indexmap": "k7_indexmap"}
 

@@ -1134,7 +1134,7 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   const uint32_t slot = s->stats_slot ^ 1u; /* the previous scan's record may not have been looked at yet */
   {
     /* one launch: the pass closes itself (last block totals and reports to the host record) */
-    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->P);
+    ProfScope ps(c, "k6k8_stats_radius", (96.0 + 81.0) * (double)c->P); /* K6 reads + K8's 81 B of products per pixel */
     c->gn_fused_report = &s->h_res[1 + slot];
     c->gn_host_seq = s->res_seq;
     /* this launch streams the three maps of the current frame: K8's per-pixel work for the update that
