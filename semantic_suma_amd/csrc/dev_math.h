@@ -148,6 +148,18 @@ __device__ __forceinline__ void rigid_inverse_dev(const float* m, float* out) {
   out[15] = 1.0f;
 }
 
+/* Streaming store for the surfel stream-out of K9 / K10 (tens of MB that nothing reads before the next pass
+ * over the map): `nt` keeps the lines from piling up dirty in the XCD's L2.  Dirty lines are written back at
+ * the END of a kernel, XCD by XCD, and the next kernel's workgroups do not start on an XCD before its
+ * write-back is done (per-block start times of K10 behind K9: 0.6 us on the first XCD, 2.3 - 5.2 us on the
+ * others; +1.4 % scans/s).  NOT for the frame maps / K8 products: the kernels that follow gather from them,
+ * and with `nt` those reads got slower than the write-back they saved (-2 %). */
+typedef float suma_v4f __attribute__((ext_vector_type(4)));
+SDEV void store_stream(float4* p, const float4& v) {
+  suma_v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<suma_v4f*>(p));
+}
+
 /* Workgroup barrier that orders LDS traffic only: __syncthreads() also drains every outstanding global
  * load / store / atomic of the wave (s_waitcnt vmcnt(0)), which turns loads issued early on purpose and
  * fire-and-forget stores into stalls.  Use where the data exchanged across the barrier lives in LDS. */

@@ -266,10 +266,10 @@ __device__ __forceinline__ bool in_active_area(const UpdArgs& a, const Surfel4& 
 
 __device__ __forceinline__ void store_surfel(suma_surfel* out, uint32_t idx, const Surfel4& s) {
   float4* o = reinterpret_cast<float4*>(out) + 4 * (size_t)idx;
-  o[0] = s.a;
-  o[1] = s.b;
-  o[2] = s.c;
-  o[3] = s.d;
+  store_stream(o, s.a);
+  store_stream(o + 1, s.b);
+  store_stream(o + 2, s.c);
+  store_stream(o + 3, s.d);
 }
 
 /* K9 for one surfel, in three stages so that a lane can keep TWO surfels in flight (the stages are
@@ -573,7 +573,7 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
       /* compacted stream-out: chunk c = (rank, 16-byte part) */
       for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
         const uint64_t d = 4ull * prefix + c;
-        if (d < 4ull * a.max_surfels) dst4[d] = s_out[pb][s_slot[pb][c >> 2]][c & 3u];
+        if (d < 4ull * a.max_surfels) store_stream(&dst4[d], s_out[pb][s_slot[pb][c >> 2]][c & 3u]);
       }
       if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
         const uint32_t tot = prefix + prev_total;
