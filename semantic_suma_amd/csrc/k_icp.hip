@@ -146,7 +146,7 @@ __device__ __forceinline__ double bcast_d(double v, int src) { /* value of lane 
 }
 
 /* JtJ.ldlt().solve(-Jtf), LieGaussNewton.cpp:60: unpivoted LDL^T in fp64 with the fixed operation order of
- * the oracle (oracle/o_icp.c, ora_solve6), the six rows of L spread over lanes 0..5 of a wave (every lane of
+ * the CPU restatement this library is tested against, the six rows of L spread over lanes 0..5 of a wave (every lane of
  * the wave runs this; lanes >= 6 shadow lane 5).  Each element goes through exactly the serial algorithm's
  * operations, in the same order -- what changes is that the five quotients of a column (and the six of
  * y / D) are formed side by side: a one-lane version spends two thirds of its instructions in 21 dependent
