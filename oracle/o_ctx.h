@@ -16,6 +16,8 @@ typedef struct ora_submap_cache {
 struct ora_ctx {
   suma_params p;
   int threads;
+  uint8_t* scratch_flags; /* per-item selection flags of the compacting passes */
+  size_t scratch_flags_cap;
 
   /* --- surfel map state (SurfelMap.h:83-208) --- */
   uint32_t timestamp; /* SurfelMap::timestamp_ */
@@ -95,5 +97,13 @@ static inline suma_float4 o_texel(const suma_float4* map, int32_t w, int32_t h, 
 
 void o_map_alloc(ora_ctx* c);
 void o_map_free(ora_ctx* c);
+
+/* depth-tested write of a 64-bit z-buffer key (smaller wins).  A min is order independent, so the point /
+ * triangle splats may run on several threads (ora_set_threads) and still give the single-thread image. */
+static inline void o_zmin(uint64_t* p, uint64_t key) {
+  uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (key < cur && !__atomic_compare_exchange_n(p, &cur, key, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+}
 
 #endif

@@ -63,6 +63,8 @@ double ora_icp_jacobian_products(ora_ctx* c, const ora_frame* current, const ora
   int64_t acc[SUMA_ACC_WORDS];
   memset(acc, 0, sizeof(acc));
 
+  /* exact integer sums: any summation order (any number of threads) gives the same words */
+#pragma omp parallel for num_threads(c->threads) schedule(static) reduction(+ : acc[:SUMA_ACC_WORDS])
   for (int32_t y = 0; y < H; ++y) {
     for (int32_t x = 0; x < W; ++x) {
       size_t pix = (size_t)y * W + x;

@@ -69,6 +69,9 @@ void o_map_alloc(ora_ctx* c) {
 }
 
 void o_map_free(ora_ctx* c) {
+  free(c->scratch_flags);
+  c->scratch_flags = NULL;
+  c->scratch_flags_cap = 0;
   free(c->surfels);
   free(c->updated);
   free(c->data_surfels);
@@ -206,7 +209,7 @@ static void o_raster_tri(o_rvtx A, o_rvtx B, o_rvtx C, int32_t W, int32_t H, uin
       if (!(z >= 0.0f && z <= 1.0f)) continue; /* near / far clipping */
       uint64_t key = o_render_key(o_depth24(z), id, tie);
       size_t pix = (size_t)j * (size_t)W + (size_t)i;
-      if (key < zbuf[pix]) zbuf[pix] = key;
+      o_zmin(&zbuf[pix], key);
     }
   }
 }
@@ -232,6 +235,7 @@ static void o_render_pass(const ora_ctx* c, const float* inv_pose, float conf_th
                           uint64_t* zbuf, int tie) {
   const ora_proj q = o_proj_model(&c->p);
   const int32_t W = (int32_t)c->p.model_width, H = (int32_t)c->p.model_height;
+#pragma omp parallel for num_threads(c->threads) schedule(dynamic, 1024)
   for (uint32_t i = 0; i < c->n_surfels; ++i) {
     const suma_surfel* s = &c->surfels[i];
     ov3 p, n;
@@ -284,6 +288,7 @@ static inline uint32_t o_key_id(uint64_t key, int tie) {
 static void o_render_resolve(const ora_ctx* c, const float* inv_pose_a, const float* inv_pose_b, const uint64_t* zbuf,
                              int tie, suma_float4* vmap, suma_float4* nmap, suma_float4* smap) {
   const size_t Pm = (size_t)c->p.model_width * c->p.model_height;
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (size_t pix = 0; pix < Pm; ++pix) {
     uint64_t key = zbuf[pix];
     if (key == O_EMPTY) {
@@ -403,6 +408,7 @@ static void o_k7_indexmap(ora_ctx* c, const float* inv_pose) {
   const int32_t W = (int32_t)c->p.data_width, H = (int32_t)c->p.data_height;
   const size_t P = (size_t)W * H;
   o_clear_zbuf(c->zbuf_data, P);
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (uint32_t i = 0; i < c->n_surfels; ++i) {
     ov3 p, n;
     o_surfel_to_sensor(c, inv_pose, &c->surfels[i], &p, &n);
@@ -415,8 +421,9 @@ static void o_k7_indexmap(ora_ctx* c, const float* inv_pose) {
     if (!(zn >= -1.0f && zn <= 1.0f)) continue;
     uint64_t key = ((uint64_t)o_depth24(0.5f * zn + 0.5f) << 32) | i;
     size_t pix = (size_t)(int32_t)fy * W + (size_t)(int32_t)fx;
-    if (key < c->zbuf_data[pix]) c->zbuf_data[pix] = key;
+    o_zmin(&c->zbuf_data[pix], key);
   }
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (size_t pix = 0; pix < P; ++pix)
     c->index_map[pix] = (c->zbuf_data[pix] == O_EMPTY) ? 0u : (uint32_t)(c->zbuf_data[pix] & 0xffffffffu) + 1u;
 }
@@ -424,6 +431,7 @@ static void o_k7_indexmap(ora_ctx* c, const float* inv_pose) {
 /* K8 init_radiusConf.vert:34-68 (quirk B-3: the confidence channel stays 0) */
 static void o_k8_radius(ora_ctx* c, const ora_frame* f, const o_map_consts* k) {
   const size_t P = (size_t)c->p.data_width * c->p.data_height;
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (size_t pix = 0; pix < P; ++pix) {
     suma_float4 v = f->vertex[pix], n = f->normal[pix];
     ov3 vv = ov3_make(v.x, v.y, v.z), nn = ov3_make(n.x, n.y, n.z);
@@ -453,6 +461,72 @@ static ov3 o_slerp(ov3 v0, ov3 v1, float weight) {
   return ov3_add(ov3_scale(w0, v0), ov3_scale(w1, v1));
 }
 
+/* Stable in-place compaction of the flagged records: chunks compact themselves side by side (a chunk only
+ * moves records towards its own start), then the chunk fronts are moved down in order. */
+#define O_CHUNK 65536u
+static uint32_t o_compact_inplace(ora_ctx* c, suma_surfel* buf, const uint8_t* flag, uint32_t n, uint32_t cap) {
+  const uint32_t nchunks = (n + O_CHUNK - 1) / O_CHUNK;
+  uint32_t* cnt = (uint32_t*)malloc((nchunks + 1) * sizeof(uint32_t));
+#pragma omp parallel for num_threads(c->threads) schedule(dynamic, 1)
+  for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    const uint32_t lo = ch * O_CHUNK, hi = (lo + O_CHUNK < n) ? lo + O_CHUNK : n;
+    uint32_t w = lo;
+    for (uint32_t i = lo; i < hi; ++i)
+      if (flag[i]) {
+        if (w != i) buf[w] = buf[i];
+        w++;
+      }
+    cnt[ch] = w - lo;
+  }
+  uint32_t n_out = 0;
+  for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    uint32_t take = cnt[ch];
+    if (n_out + take > cap) take = cap - n_out; /* TF buffer full: later records are dropped */
+    if (take && n_out != ch * O_CHUNK) memmove(buf + n_out, buf + (size_t)ch * O_CHUNK, (size_t)take * sizeof(suma_surfel));
+    n_out += take;
+  }
+  free(cnt);
+  return n_out;
+}
+
+/* stable compaction of the flagged records of src behind dst[0 .. n_out): counts per chunk, prefix, copies */
+static uint32_t o_compact_copy(ora_ctx* c, suma_surfel* dst, uint32_t n_out, const suma_surfel* src,
+                               const uint8_t* flag, uint32_t n, uint32_t cap) {
+  const uint32_t nchunks = (n + O_CHUNK - 1) / O_CHUNK;
+  uint32_t* off = (uint32_t*)malloc((nchunks + 1) * sizeof(uint32_t));
+#pragma omp parallel for num_threads(c->threads) schedule(static)
+  for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    const uint32_t lo = ch * O_CHUNK, hi = (lo + O_CHUNK < n) ? lo + O_CHUNK : n;
+    uint32_t k = 0;
+    for (uint32_t i = lo; i < hi; ++i) k += flag[i];
+    off[ch + 1] = k;
+  }
+  off[0] = n_out;
+  for (uint32_t ch = 0; ch < nchunks; ++ch) off[ch + 1] += off[ch];
+#pragma omp parallel for num_threads(c->threads) schedule(dynamic, 1)
+  for (uint32_t ch = 0; ch < nchunks; ++ch) {
+    const uint32_t lo = ch * O_CHUNK, hi = (lo + O_CHUNK < n) ? lo + O_CHUNK : n;
+    uint32_t w = off[ch];
+    for (uint32_t i = lo; i < hi; ++i)
+      if (flag[i]) {
+        if (w < cap) dst[w] = src[i];
+        w++;
+      }
+  }
+  uint32_t total = off[nchunks];
+  free(off);
+  return total < cap ? total : cap;
+}
+
+static uint8_t* o_scratch_flags(ora_ctx* c, size_t n) {
+  if (c->scratch_flags_cap < n) {
+    free(c->scratch_flags);
+    c->scratch_flags_cap = n + n / 4 + 1024;
+    c->scratch_flags = (uint8_t*)malloc(c->scratch_flags_cap);
+  }
+  return c->scratch_flags;
+}
+
 /* K9 update_surfels.vert:140-334 + update_surfels.geom:30-43 (emit iff valid) +
  * update_surfels.frag:9-12 (integration mask), output stable in input order (transform feedback). */
 static void o_k9_update(ora_ctx* c, const float* pose, const float* inv_pose, const ora_frame* f,
@@ -463,7 +537,10 @@ static void o_k9_update(ora_ctx* c, const float* pose, const float* inv_pose, co
   const int32_t timestamp = (int32_t)c->timestamp;
   const float upper_stability_bound = 20.0f;
   memset(c->integrated, 0, (size_t)W * H);
-  uint32_t n_out = 0;
+  /* phase 1 (any number of threads): surfel i -> its updated record at updated[i] + keep flag;
+   * phase 2: stable compaction in input order, as the transform feedback delivers it */
+  uint8_t* keep_flag = o_scratch_flags(c, c->n_surfels);
+#pragma omp parallel for num_threads(c->threads) schedule(dynamic, 2048)
   for (uint32_t i = 0; i < c->n_surfels; ++i) {
     const suma_surfel in = c->surfels[i];
     int32_t surfel_age = timestamp - (int32_t)in.timestamp;
@@ -589,12 +666,13 @@ static void o_k9_update(ora_ctx* c, const float* pose, const float* inv_pose, co
        * unless z_ndc = 2*z01 - 1 lies in [-1, 1] (x, y are texel centres inside the viewport) */
       if (mark_pixel) {
         float zn = 2.0f * imz - 1.0f;
-        if (zn >= -1.0f && zn <= 1.0f) c->integrated[(size_t)ty * W + tx] = 1;
+        if (zn >= -1.0f && zn <= 1.0f) __atomic_store_n(&c->integrated[(size_t)ty * W + tx], (uint8_t)1, __ATOMIC_RELAXED);
       }
-      if (n_out < p->max_surfels) c->updated[n_out++] = out;
+      c->updated[i] = out;
     }
+    keep_flag[i] = (uint8_t)(keep != 0);
   }
-  c->n_updated = n_out;
+  c->n_updated = o_compact_inplace(c, c->updated, keep_flag, c->n_surfels, p->max_surfels);
 }
 
 /* K10 gen_surfels.vert:38-52 + gen_surfels.geom:109-145; emission order = vbo_img_coords_
@@ -656,12 +734,14 @@ static void o_k11_copy(ora_ctx* c) {
   for (int src = 0; src < 2; ++src) {
     const suma_surfel* buf = src == 0 ? c->updated : c->data_surfels;
     uint32_t n = src == 0 ? c->n_updated : c->n_data;
+    uint8_t* sel = o_scratch_flags(c, n);
+#pragma omp parallel for num_threads(c->threads) schedule(static)
     for (uint32_t i = 0; i < n; ++i) {
       const suma_surfel* s = &buf[i];
       ov3 pos = om4_point(c->poses + 16 * (size_t)(int32_t)s->count, ov3_make(s->x, s->y, s->z));
-      if ((int32_t)s->timestamp < 0 || fabsf(pos.x - cx) > extent || fabsf(pos.y - cy) > extent) continue;
-      if (n_out < c->p.max_surfels) c->surfels[n_out++] = *s;
+      sel[i] = !((int32_t)s->timestamp < 0 || fabsf(pos.x - cx) > extent || fabsf(pos.y - cy) > extent);
     }
+    n_out = o_compact_copy(c, c->surfels, n_out, buf, sel, n, c->p.max_surfels);
   }
   c->n_surfels = n_out;
 }

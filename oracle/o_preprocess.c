@@ -29,6 +29,7 @@ static void o_k1_vertexmap(const ora_ctx* c, const suma_float4* pts, const float
   const size_t P = (size_t)W * (size_t)H;
   for (size_t i = 0; i < P; ++i) zbuf[i] = ~(uint64_t)0;
 
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (uint32_t i = 0; i < n; ++i) {
     ov3 pos = ov3_make(pts[i].x, pts[i].y, pts[i].z);
     float depth = ov3_len(pos);
@@ -44,10 +45,11 @@ static void o_k1_vertexmap(const ora_ctx* c, const suma_float4* pts, const float
     float zw = 0.5f * z + 0.5f;
     uint64_t key = ((uint64_t)o_depth24(zw) << 32) | (uint64_t)i;
     size_t pix = (size_t)(int32_t)fy * (size_t)W + (size_t)(int32_t)fx;
-    if (key < zbuf[pix]) zbuf[pix] = key;
+    o_zmin(&zbuf[pix], key);
   }
 
   const int isfirst = (timestamp < 10); /* Preprocessing.cpp:176-179 */
+#pragma omp parallel for num_threads(c->threads) schedule(static)
   for (size_t pix = 0; pix < P; ++pix) {
     uint64_t key = zbuf[pix];
     if (key == ~(uint64_t)0) {

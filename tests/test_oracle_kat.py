@@ -162,3 +162,17 @@ def test_label_offset_quirk(oracle_lib):
         hit = np.argwhere(f.vertex[..., 0] == 10.0)
         assert len(hit) == 1
         assert sem[tuple(hit[0])][0] == np.float32(expect) / np.float32(255.0)
+
+
+def test_oracle_threads_are_bit_identical(oracle_lib):
+    """ora_set_threads: integer sums, z-buffer minima and stable compactions do not depend on the thread count."""
+    from semantic_suma_amd import synth
+    p = params_with_size(360, height=32)
+    res = []
+    for th in (1, 4):
+        op = oracle_lib.OraclePipeline(p, threads=th)
+        for k in range(4):
+            pts, lab, prob, _ = synth.generate_scan(k, n_azimuth=360, height=32)
+            op.process_scan(pts, lab, prob, fixed_iterations=5)
+        res.append((op.pose().tobytes(), op.ctx.map_surfels().tobytes(), op.last_stats().as_dict()))
+    assert res[0] == res[1]
