@@ -222,7 +222,7 @@ def main():
         # (a) the sequential restatement, (b) the same code with OpenMP over pixels / surfels (bit-identical
         # results: integer sums, z-buffer minima and stable compactions are order independent)
         ncores = os.cpu_count() or 1
-        threads = max(1, min(ncores, 64))
+        threads = max(1, min(ncores, 16))  # tools/oracle_scaling.py on the 256-core MI355X host: 8 -> 29, 16 -> 48, 32 -> 36, 64 -> 24 scans/s
         sample = f"first {n_cpu} scans of the same {H}x{W} sequence through oracle/"
         out["cpu_baseline"] = {"value": time_oracle(threads), "unit": "scans/s", "cores": threads, "kind": "port",
                                "sample": f"{sample} (OpenMP, {threads} threads of {ncores} host cores)"}
