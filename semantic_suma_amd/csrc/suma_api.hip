@@ -290,7 +290,6 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
     CK(hipHostMalloc((void**)&c->h_gn, SUMA_MAX_HYP * sizeof(GnState), hipHostMallocDefault));
     CK(hipMalloc((void**)&c->pose_block, 32 * sizeof(float)));
-    CK(hipEventCreateWithFlags(&c->ev_result, hipEventDisableTiming));
     c->gn_emit_pose = 0;
     c->gn_host_out = nullptr;
     c->gn_fused_report = nullptr;
@@ -337,7 +336,6 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.b);
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
-  if (c->ev_result) hipEventDestroy(c->ev_result);
   void* dev[] = {c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,

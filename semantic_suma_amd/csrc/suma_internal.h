@@ -125,7 +125,6 @@ struct suma_ctx {
   int gn_emit_pose;        /* the closing launch of the chain being enqueued writes pose_block */
   double gn_pose_base[16];
   float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
-  hipEvent_t ev_result;    /* recorded after the minimisation result has been copied to the host */
   int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
   uint32_t gn_iteration0;
   double gn_T0_host[16];
