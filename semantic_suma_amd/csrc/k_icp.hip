@@ -71,11 +71,19 @@ __device__ __forceinline__ float4 bilinear_fetch(const float4* __restrict__ map,
 
 /* raw magic-number bits of round(term * 2^28); MAGIC_BITS is subtracted once per term after the
  * reduction (count * MAGIC_BITS, modulo 2^64) */
-__device__ __forceinline__ long long fix_bits(float term) {
+__device__ __forceinline__ long long fix_bits(float term, double scale, double magic) {
   /* one v_fma_f64: the product with 2^28 is exact, so fusing changes nothing numerically (this
-   * file is otherwise compiled with -ffp-contract=off, which would split it into ldexp + add) */
-  double d = __builtin_fma((double)term, SUMA_ACC_SCALE, MAGIC_D);
+   * file is otherwise compiled with -ffp-contract=off, which would split it into ldexp + add).
+   * scale = 2^28 and magic = 1.5 * 2^52 are passed in REGISTERS (see fix_consts): with literal operands the
+   * compiler emits a destructive v_fmac_f64 and re-materialises the magic number with two v_mov per term. */
+  double d = __builtin_fma((double)term, scale, magic);
   return __double_as_longlong(d);
+}
+__device__ __forceinline__ void fix_consts(double* scale, double* magic) {
+  double sc = SUMA_ACC_SCALE, mg = MAGIC_D;
+  asm volatile("" : "+v"(sc), "+v"(mg)); /* opaque: keeps both in VGPR pairs */
+  *scale = sc;
+  *magic = mg;
 }
 
 __device__ __forceinline__ long long shfl_xor_ll(long long v, int mask) {
@@ -551,6 +559,8 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   long long acc[SUMA_ACC_WORDS];
 #pragma unroll
   for (int i = 0; i < SUMA_ACC_WORDS; ++i) acc[i] = 0;
+  double fx_scale, fx_magic;
+  fix_consts(&fx_scale, &fx_magic);
 
   const float fWm = (float)a.Wm, fHm = (float)a.Hm;
   for (uint32_t pix = pix0; pix < a.P; pix += gridDim.x * ICP_THREADS) {
@@ -628,7 +638,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
           weight *= data_prob;
       }
       float wr2 = (weight * residual) * residual;
-      acc[27] += fix_bits(wr2);
+      acc[27] += fix_bits(wr2, fx_scale, fx_magic);
       acc[29] += 1;
       if (inlier) {
         const float J[6] = {n_m.x, n_m.y, n_m.z, cp.x, cp.y, cp.z};
@@ -637,12 +647,12 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         for (int i = 0; i < 6; ++i) {
           float wJi = weight * J[i];
 #pragma unroll
-          for (int j = i; j < 6; ++j) acc[k++] += fix_bits(wJi * J[j]);
+          for (int j = i; j < 6; ++j) acc[k++] += fix_bits(wJi * J[j], fx_scale, fx_magic);
         }
         float wr = weight * residual;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += fix_bits(wr * J[i]);
-        acc[28] += fix_bits(wr2);
+        for (int i = 0; i < 6; ++i) acc[21 + i] += fix_bits(wr * J[i], fx_scale, fx_magic);
+        acc[28] += fix_bits(wr2, fx_scale, fx_magic);
       } else {
         acc[30] += 1;
       }
