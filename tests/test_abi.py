@@ -86,3 +86,13 @@ def test_cpp_adapter_compiles_and_links(built, tmp_path):
     import torch
     rc = subprocess.call([str(exe)])
     assert rc == (0 if torch.cuda.is_available() else 42)  # throws like the reference when there is no device
+
+
+def test_c_example_compiles_and_links(built, tmp_path):
+    """examples/odometry.c: a plain C99 host program on the C-ABI; without arguments it prints its usage"""
+    exe = tmp_path / "odometry"
+    libdir = os.path.dirname(built.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-O1", "-Wall", "-Wextra", "-Werror", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "odometry.c"), "-o", str(exe),
+                           "-L", libdir, "-lsuma_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    assert subprocess.call([str(exe)], stderr=subprocess.DEVNULL) == 2
