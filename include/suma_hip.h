@@ -12,7 +12,9 @@
  *  - return value: 0 = SUMA_OK, negative = error (suma_last_error() gives the text).
  *  - one suma_ctx = one HIP device + one HIP stream; calls on a ctx are serialised by the caller
  *    (as in the reference, whose methods all run on the thread that owns the GL context);
- *    different ctxs may be driven from different threads / processes (one per GPU).
+ *    different ctxs may be driven from different threads / processes (one per GPU).  suma_ctx_create makes its
+ *    device the calling thread's current HIP device; a thread that drives ctxs on DIFFERENT devices must make the
+ *    ctx's device current (hipSetDevice) before calling into it -- the entry points do not switch devices.
  *  - matrices are column-major 4x4 (Eigen::Matrix4f / Matrix4d default storage).
  *  - host pointers unless the name says _device.
  *  - there is NO CPU fallback: without a gfx950 device suma_ctx_create fails.
