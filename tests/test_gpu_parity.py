@@ -328,6 +328,30 @@ def test_pipeline_fallback_icp(hip, oracle_lib):
     assert op.track_loss() >= 1, "the sequence was meant to trip the fallback"
 
 
+@pytest.mark.parametrize("overrides", [
+    dict(weighting_scheme=1, averaging_scheme=0),                  # running weights, averaged position
+    dict(weighting_scheme=2, averaging_scheme=1, update_always=1), # view-angle weights, push along the normal
+    dict(confidence_mode=0),                                       # constant p_stable
+    dict(confidence_mode=1),                                       # angle term only
+    dict(confidence_mode=2, weight_function=2),                    # distance term only, Tukey ICP weights
+    dict(use_stability=0),                                         # no stability gating in K4 / K9
+    dict(partial_extraction=0),                                    # submap extraction in one go
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_pipeline_update_variants(hip, oracle_lib, overrides):
+    """the switches of update_surfels.vert / SurfelMap.cpp that default.xml leaves off: same maps as the oracle"""
+    p = params_with_size(900, **overrides)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    for k in range(4):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=6)
+        op.process_scan(pts, lab, prob, fixed_iterations=6)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k}: pose bits"
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"scan {k} stats"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        frames_equal(hp.frame(2), op.frame(2), f"scan {k} model frame")
+
+
 def test_pipeline_convergence_mode(hip, oracle_lib):
     """default.xml stopping tests (no fixed iteration count), no semantics: BASELINE config 1 style"""
     p = params_with_size(900, max_iterations=10)
