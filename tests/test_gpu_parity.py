@@ -336,6 +336,9 @@ def test_pipeline_fallback_icp(hip, oracle_lib):
     dict(confidence_mode=2, weight_function=2),                    # distance term only, Tukey ICP weights
     dict(use_stability=0),                                         # no stability gating in K4 / K9
     dict(partial_extraction=0),                                    # submap extraction in one go
+    dict(initialize_identity=1),                                   # ICP starts from identity, not the last increment
+    dict(compose_rendering=0),                                     # SurfelMap::render without the old/new composition
+    dict(fallback_mode=0, icp_max_distance=1.0, icp_max_angle=20.0),
 ], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
 def test_pipeline_update_variants(hip, oracle_lib, overrides):
     """the switches of update_surfels.vert / SurfelMap.cpp that default.xml leaves off: same maps as the oracle"""
