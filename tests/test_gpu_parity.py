@@ -355,6 +355,31 @@ def test_pipeline_update_variants(hip, oracle_lib, overrides):
         frames_equal(hp.frame(2), op.frame(2), f"scan {k} model frame")
 
 
+def test_pipeline_scans_with_nan_and_inf_points(hip, oracle_lib):
+    """sensor drop-outs delivered as NaN / +-inf / zero points are clipped by K1's range and image tests
+    (gen_vertexmap.vert:88-93: nothing is written for them) -- identically on both sides"""
+    p = params_with_size(900)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    rng = np.random.default_rng(99)
+    for k in range(4):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        pts = pts.copy()
+        bad = rng.choice(pts.shape[0], size=pts.shape[0] // 25, replace=False)
+        pts[bad[0::4], 0] = np.nan
+        pts[bad[1::4], 1] = np.inf
+        pts[bad[2::4], 2] = -np.inf
+        pts[bad[3::4], :3] = 0.0
+        hp.processScan(pts, lab, prob, fixed_iterations=6)
+        op.process_scan(pts, lab, prob, fixed_iterations=6)
+        assert np.all(np.isfinite(op.pose()))
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k}: pose bits"
+        assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"scan {k} stats"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        for w in (0, 1, 2):
+            frames_equal(hp.frame(w), op.frame(w), f"scan {k} frame {w}")
+
+
 def test_pipeline_convergence_mode(hip, oracle_lib):
     """default.xml stopping tests (no fixed iteration count), no semantics: BASELINE config 1 style"""
     p = params_with_size(900, max_iterations=10)
