@@ -244,6 +244,53 @@ def test_surfel_map_update_and_render_2048(hip, oracle_lib):
     _run_maps(hip, oracle_lib, params_with_size(2048), 2048, 3)
 
 
+def test_surfel_map_update_poses(hip, oracle_lib):
+    """SurfelMap::updatePoses (SurfelMap.cpp:486-490): after a pose-graph optimisation the map is deformed by
+    re-uploading the pose table only; rendering and the next update then see the surfels at their new places"""
+    p = params_with_size(900)
+    n = 4
+    ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, n)
+    T0 = get_scan(0, 900, True)[3]
+    poses = []
+    for i in range(n):
+        T = np.linalg.inv(T0) @ get_scan(i, 900, True)[3]
+        D = np.eye(4)  # a smooth "optimised" correction growing along the trajectory
+        a = 0.002 * i
+        D[:3, :3] = [[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]]
+        D[:3, 3] = [0.01 * i, -0.005 * i, 0.002 * i]
+        poses.append((D @ T).astype(np.float32))
+    hmap.updatePoses(poses)
+    ora.map_update_poses(np.stack(poses))
+    pose = poses[-1]
+    hout = hip.Frame(ctx, p.model_width, p.model_height)
+    oout = ora.frame(model=True)
+    hmap.render(pose, pose, hout, 0.0)
+    ora.map_render(pose, pose, 0.0, oout)
+    frames_equal(hout, oout, "render after updatePoses")
+    # ... and the next scan is fused into the deformed map
+    pts, lab, prob, T = get_scan(n, 900, True)
+    hf = hip.Frame(ctx, 900, 64)
+    hip.Preprocessing(ctx).process(pts, hf, lab, prob, n)
+    of = ora.preprocess(pts, lab, prob, n, ora.frame())
+    pose_n = (np.linalg.inv(T0) @ T)
+    hmap.update(pose_n, hf)
+    ora.map_update(pose_n, of)
+    assert hmap.getAllSurfels().tobytes() == ora.map_surfels().tobytes()
+
+
+def test_pipeline_device_scans_equal_host_scans(hip):
+    """suma_pipeline_process_scan_device (scans already in HBM) == suma_pipeline_process_scan (host pointers)"""
+    p = params_with_size(900)
+    a, b = hip.SurfelMapping(p), hip.SurfelMapping(p)
+    for k in range(3):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        a.processScan(pts, lab, prob, fixed_iterations=5)
+        d = (b.ctx.device_array(pts), b.ctx.device_array(lab), b.ctx.device_array(prob))
+        b.processScanDevice(*d, pts.shape[0], fixed_iterations=5)
+        assert np.array_equal(a.getCurrentPose(), b.getCurrentPose())
+        assert a.map.getAllSurfels().tobytes() == b.map.getAllSurfels().tobytes()
+
+
 def test_surfel_map_render_variants(hip, oracle_lib):
     p = params_with_size(900)
     ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 3)
