@@ -42,6 +42,9 @@ struct ora_ctx {
   uint32_t n_caches, cap_caches;
   int32_t* extraction; /* pending (i,j) pairs, used as a stack */
   uint32_t n_extraction, cap_extraction;
+  /* record of the last K12 extraction, for stage-by-stage tests */
+  int32_t last_extract_i, last_extract_j;
+  uint32_t n_extractions_done;
 };
 
 /* derived constants, computed the way the reference's setParameters() compute them */

@@ -33,14 +33,16 @@ static o_map_consts o_consts(const suma_params* p) {
   o_map_consts k;
   float vfov = fabsf(p->data_fov_up) + fabsf(p->data_fov_down);
   float hfov = 360.0f;
-  float vpix = (float)tan((double)(0.5f * o_deg2rad(vfov) / (float)p->data_height));
-  float hpix = (float)tan((double)(0.5f * o_deg2rad(hfov) / (float)p->data_width));
+  /* SurfelMap.cpp:342-343: rv::Math::deg2rad is double (Math.h:44-47) -> the argument is evaluated in double */
+  float vpix = (float)tan(0.5 * ((double)vfov * M_PI / 180.0) / (double)p->data_height);
+  float hpix = (float)tan(0.5 * ((double)hfov * M_PI / 180.0) / (double)p->data_width);
   k.pixel_size = of_max(vpix, hpix);
   k.p_unstable = 1.0f - p->p_stable;
   k.log_prior = (float)log((double)p->p_prior / (1.0 - (double)p->p_prior));
   k.log_unstable = (float)log((double)k.p_unstable / (1.0 - (double)k.p_unstable));
   k.radconf_angle_thresh = (float)cos((double)o_deg2rad(p->max_angle));    /* :394-397 */
-  k.update_angle_thresh = (float)sin((double)o_deg2rad(p->map_max_angle)); /* :407 */
+  /* :407 std::sin(Radians(float)): rv/geometry.h:81-84 evaluates ((float)M_PI / 180.f) * deg in float; sinf */
+  k.update_angle_thresh = sinf(((float)M_PI / 180.f) * p->map_max_angle);
   return k;
 }
 
@@ -105,6 +107,7 @@ void ora_map_reset(ora_ctx* c) {
   for (uint32_t i = 0; i < c->n_caches; ++i) free(c->caches[i].surfels);
   c->n_caches = 0;
   c->n_extraction = 0;
+  c->n_extractions_done = 0;
   c->origin_i = c->origin_j = 0;
 }
 
@@ -129,6 +132,25 @@ void ora_map_upload(ora_ctx* c, const suma_surfel* s, uint32_t n, uint32_t times
   memcpy(c->surfels, s, (size_t)n * sizeof(suma_surfel));
   c->n_surfels = n;
   c->timestamp = timestamp;
+}
+const suma_surfel* ora_map_updated_surfels(const ora_ctx* c) { return c->updated; }
+const suma_surfel* ora_map_data_surfels(const ora_ctx* c) { return c->data_surfels; }
+const float* ora_map_poses(const ora_ctx* c) { return c->poses; }
+uint32_t ora_map_pending_extractions(const ora_ctx* c) { return c->n_extraction; }
+/* tile (i, j) of the submap cache: records and count (NULL / 0 when the tile was never extracted) */
+const suma_surfel* ora_map_cache_tile(const ora_ctx* c, int32_t i, int32_t j, uint32_t* n) {
+  for (uint32_t k = 0; k < c->n_caches; ++k)
+    if (c->caches[k].i == i && c->caches[k].j == j) {
+      *n = c->caches[k].n;
+      return c->caches[k].surfels;
+    }
+  *n = 0;
+  return NULL;
+}
+uint32_t ora_map_last_extraction(const ora_ctx* c, int32_t* ij) {
+  ij[0] = c->last_extract_i;
+  ij[1] = c->last_extract_j;
+  return c->n_extractions_done;
 }
 uint32_t ora_map_cached_surfels(const ora_ctx* c) {
   uint32_t s = 0;
@@ -231,44 +253,56 @@ static int o_render_selects(const ora_ctx* c, const suma_surfel* s, int mode, in
   return (creation >= thr || ts >= thr); /* render_surfels.geom:90-91 */
 }
 
+/* render_surfels.vert:42-54 + render_surfels.geom:76-123 for one surfel: gate and the four strip corners in
+ * [0,1]^3 (x unwrapped relative to the centre, .geom:67-69).  Returns 1 when the quad is emitted. */
+static int o_render_quad(const ora_ctx* c, const ora_proj* q, const float* inv_pose, float conf_threshold, int mode,
+                         int32_t thr, const suma_surfel* s, ov3* p_out, ov3* n_out, ov3 pr[4]) {
+  ov3 p, n;
+  o_surfel_to_sensor(c, inv_pose, s, &p, &n);
+  *p_out = p;
+  *n_out = n;
+  ov3 u = ov3_normalize(ov3_make(n.y - n.z, -n.x, n.x));
+  ov3 v = ov3_normalize(ov3_cross(n, u));
+  float r = s->radius;
+  float lp = ov3_len(p);
+  int visible = ov3_dot(n, ov3_divs(ov3_neg(p), lp)) > 0.01f;
+  ov3 pp = o_project01(q, p);
+  if (!(visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f &&
+        (!c->p.use_stability || s->confidence > conf_threshold)))
+    return 0;
+  if (!o_render_selects(c, s, mode, thr)) return 0;
+  ov3 ru = ov3_scale(r, u), rv = ov3_scale(r, v);
+  ov3 corner[4];
+  corner[0] = ov3_sub(ov3_sub(p, ru), rv);
+  corner[1] = ov3_sub(ov3_add(p, ru), rv);
+  corner[2] = ov3_add(ov3_sub(p, ru), rv);
+  corner[3] = ov3_add(ov3_add(p, ru), rv);
+  for (int k = 0; k < 4; ++k) {
+    pr[k] = o_project01(q, corner[k]);
+    /* render_surfels.geom:67-69 seam hack */
+    if (pp.x - pr[k].x > 0.5f) pr[k].x += 1.0f;
+    if (pr[k].x - pp.x > 0.5f) pr[k].x -= 1.0f;
+  }
+  return 1;
+}
+
 static void o_render_pass(const ora_ctx* c, const float* inv_pose, float conf_threshold, int mode, int32_t thr,
                           uint64_t* zbuf, int tie) {
   const ora_proj q = o_proj_model(&c->p);
   const int32_t W = (int32_t)c->p.model_width, H = (int32_t)c->p.model_height;
 #pragma omp parallel for num_threads(c->threads) schedule(dynamic, 1024)
   for (uint32_t i = 0; i < c->n_surfels; ++i) {
-    const suma_surfel* s = &c->surfels[i];
-    ov3 p, n;
-    o_surfel_to_sensor(c, inv_pose, s, &p, &n);
-    ov3 u = ov3_normalize(ov3_make(n.y - n.z, -n.x, n.x));
-    ov3 v = ov3_normalize(ov3_cross(n, u));
-    float r = s->radius;
-    float lp = ov3_len(p);
-    int visible = ov3_dot(n, ov3_divs(ov3_neg(p), lp)) > 0.01f;
-    ov3 pp = o_project01(&q, p);
-    if (!(visible && pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f &&
-          (!c->p.use_stability || s->confidence > conf_threshold)))
-      continue;
-    if (!o_render_selects(c, s, mode, thr)) continue;
-    ov3 ru = ov3_scale(r, u), rv = ov3_scale(r, v);
-    ov3 corner[4];
-    corner[0] = ov3_sub(ov3_sub(p, ru), rv);
-    corner[1] = ov3_sub(ov3_add(p, ru), rv);
-    corner[2] = ov3_add(ov3_sub(p, ru), rv);
-    corner[3] = ov3_add(ov3_add(p, ru), rv);
+    ov3 p, n, pr[4];
+    if (!o_render_quad(c, &q, inv_pose, conf_threshold, mode, thr, &c->surfels[i], &p, &n, pr)) continue;
     static const float tcu[4] = {-1.f, 1.f, -1.f, 1.f}, tcv[4] = {-1.f, -1.f, 1.f, 1.f};
     o_rvtx vt[4];
     int bad = 0;
     for (int k = 0; k < 4; ++k) {
-      ov3 pr = o_project01(&q, corner[k]);
-      /* render_surfels.geom:67-69 seam hack */
-      if (pp.x - pr.x > 0.5f) pr.x += 1.0f;
-      if (pr.x - pp.x > 0.5f) pr.x -= 1.0f;
-      float xw = pr.x * q.width, yw = pr.y * q.height;
-      if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr.z)) bad = 1;
+      float xw = pr[k].x * q.width, yw = pr[k].y * q.height;
+      if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr[k].z)) bad = 1;
       vt[k].X = (int64_t)sdm_floor(xw * 256.0f + 0.5f);
       vt[k].Y = (int64_t)sdm_floor(yw * 256.0f + 0.5f);
-      vt[k].z = pr.z;
+      vt[k].z = pr[k].z;
       vt[k].tu = tcu[k];
       vt[k].tv = tcv[k];
     }
@@ -276,6 +310,31 @@ static void o_render_pass(const ora_ctx* c, const float* inv_pose, float conf_th
     /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
     o_raster_tri(vt[0], vt[1], vt[2], W, H, zbuf, i, tie);
     o_raster_tri(vt[2], vt[1], vt[3], W, H, zbuf, i, tie);
+  }
+}
+
+/* stage export for tests/test_ref_shaders.py: what K4's vertex + geometry stage produce per surfel, before
+ * rasterisation.  mode / thr as in o_render_pass; corners = 4 x (x01, y01, z01); pn = sensor-frame position, normal */
+void ora_debug_render_quads(const ora_ctx* c, const float pose[16], float conf_threshold, int mode, int32_t thr,
+                            uint8_t* emitted, float* corners, float* pn) {
+  const ora_proj q = o_proj_model(&c->p);
+  float inv_pose[16];
+  om4_rigid_inverse(pose, inv_pose);
+  for (uint32_t i = 0; i < c->n_surfels; ++i) {
+    ov3 p, n, pr[4];
+    memset(pr, 0, sizeof(pr));
+    emitted[i] = (uint8_t)o_render_quad(c, &q, inv_pose, conf_threshold, mode, thr, &c->surfels[i], &p, &n, pr);
+    for (int k = 0; k < 4; ++k) {
+      corners[12 * (size_t)i + 3 * k] = pr[k].x;
+      corners[12 * (size_t)i + 3 * k + 1] = pr[k].y;
+      corners[12 * (size_t)i + 3 * k + 2] = pr[k].z;
+    }
+    pn[6 * (size_t)i] = p.x;
+    pn[6 * (size_t)i + 1] = p.y;
+    pn[6 * (size_t)i + 2] = p.z;
+    pn[6 * (size_t)i + 3] = n.x;
+    pn[6 * (size_t)i + 4] = n.y;
+    pn[6 * (size_t)i + 5] = n.z;
   }
 }
 
@@ -794,6 +853,9 @@ static void o_extract(ora_ctx* c, int partially) {
     }
     e->n = n;
     e->surfels = (suma_surfel*)realloc(e->surfels, (size_t)(n ? n : 1) * sizeof(suma_surfel));
+    c->last_extract_i = i;
+    c->last_extract_j = j;
+    c->n_extractions_done++;
     if (partially) break;
   }
 }

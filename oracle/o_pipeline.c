@@ -168,7 +168,7 @@ static void o_update_pose(ora_pipeline* s, int32_t fixed_iterations) {
   float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
   float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));
   float r_err = (float)acos((double)fmaxf(fminf(angle, 1.0f), -1.0f));
-  if (s->timestamp > 1 && (t_err > 0.4f || r_err > 0.1f) && c->p.fallback_mode) { /* :438-449 */
+  if (s->timestamp > 1 && ((double)t_err > 0.4 || (double)r_err > 0.1) && c->p.fallback_mode) { /* :438-449: float against the double literals */
     s->track_loss += 1;
     suma_params saved = c->p;
     c->p.icp_max_distance = c->p.fallback_max_distance;

@@ -78,6 +78,16 @@ def lib(variant: str = ""):
         getattr(L, n).restype = C.c_uint32
         getattr(L, n).argtypes = [vp]
     L.ora_map_submap_origin.argtypes = [vp, vp]
+    for n in ("ora_map_updated_surfels", "ora_map_data_surfels", "ora_map_poses"):
+        getattr(L, n).restype = vp
+        getattr(L, n).argtypes = [vp]
+    L.ora_map_pending_extractions.restype = C.c_uint32
+    L.ora_map_pending_extractions.argtypes = [vp]
+    L.ora_map_cache_tile.restype = vp
+    L.ora_map_cache_tile.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint32)]
+    L.ora_map_last_extraction.restype = C.c_uint32
+    L.ora_map_last_extraction.argtypes = [vp, vp]
+    L.ora_debug_render_quads.argtypes = [vp, vp, C.c_float, C.c_int, C.c_int32, vp, vp, vp]
     L.ora_pipeline_create.restype = vp
     L.ora_pipeline_create.argtypes = [C.POINTER(SumaParams)]
     L.ora_pipeline_destroy.argtypes = [vp]
@@ -268,6 +278,48 @@ class Oracle:
 
     def map_cached_surfels(self):
         return self.L.ora_map_cached_surfels(self.h)
+
+    # -- stage exports (tests/test_ref_shaders.py)
+    def map_updated_surfels(self) -> np.ndarray:
+        """K9 output of the last update (S' records, before K11)"""
+        n = self.L.ora_map_last_updated_count(self.h)
+        return _view(self.L.ora_map_updated_surfels(self.h), (max(n, 1),), SURFEL_DTYPE)[:n].copy()
+
+    def map_data_surfels(self) -> np.ndarray:
+        """K10 output of the last update (D records, before K11)"""
+        n = self.L.ora_map_last_new_count(self.h)
+        return _view(self.L.ora_map_data_surfels(self.h), (max(n, 1),), SURFEL_DTYPE)[:n].copy()
+
+    def map_poses(self, n=None) -> np.ndarray:
+        """pose table as stored (column-major 4x4 floats), n x 16"""
+        n = self.params.max_poses if n is None else n
+        return _view(self.L.ora_map_poses(self.h), (n, 16), np.float32).copy()
+
+    def map_pending_extractions(self):
+        return self.L.ora_map_pending_extractions(self.h)
+
+    def map_cache_tile(self, i, j) -> np.ndarray:
+        n = C.c_uint32(0)
+        ptr = self.L.ora_map_cache_tile(self.h, i, j, C.byref(n))
+        if not ptr or n.value == 0:
+            return np.zeros(0, dtype=SURFEL_DTYPE)
+        return _view(ptr, (n.value,), SURFEL_DTYPE).copy()
+
+    def map_last_extraction(self):
+        """(number of K12 extractions so far, (i, j) of the last one)"""
+        ij = np.zeros(2, dtype=np.int32)
+        n = self.L.ora_map_last_extraction(self.h, _ptr(ij))
+        return n, (int(ij[0]), int(ij[1]))
+
+    def debug_render_quads(self, pose, conf_threshold, mode, thr):
+        """K4 vertex + geometry stage per surfel: (emitted, corners[n,4,3] in [0,1]^3, sensor-frame pos/normal[n,6])"""
+        n = self.map_size()
+        po = np.ascontiguousarray(np.asarray(pose, dtype=np.float32).T)
+        emitted = np.zeros(max(n, 1), dtype=np.uint8)
+        corners = np.zeros((max(n, 1), 4, 3), dtype=np.float32)
+        pn = np.zeros((max(n, 1), 6), dtype=np.float32)
+        self.L.ora_debug_render_quads(self.h, _ptr(po), conf_threshold, mode, thr, _ptr(emitted), _ptr(corners), _ptr(pn))
+        return emitted[:n], corners[:n], pn[:n]
 
     def map_submap_origin(self):
         ij = np.zeros(2, dtype=np.int32)

@@ -2,10 +2,13 @@
  * oracle/suma_oracle.h -- TEST INFRASTRUCTURE.  CPU restatement of the SuMa++ projective-ICP +
  * surfel-fusion hot path (reference: PRBonn/semantic_suma, src/core + src/shader).
  *
- * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures and
- * cannot be built or run here (needs an OpenGL context, glow, Eigen, gtsam, Qt).  This oracle is
- * a line-by-line restatement of the GLSL shaders and their host call sites; each function cites
- * the file:line it follows.  It is pinned only by analytic known-answer tests (tests/test_oracle_kat.py).
+ * PINNED TO THE REFERENCE'S SOURCE TEXT: the reference ships no tests, golden vectors or fixtures
+ * and its host side cannot be built here (OpenGL context, glow, Eigen, gtsam, Qt), but its GLSL shaders and
+ * lie_algebra.cpp are compiled with g++ where they lie (oracle/ref_build.py -> oracle/_ref/libsuma_ref.so) and
+ * tests/test_ref_shaders.py demands equal values between them and this restatement for every stage (K1-K12) on
+ * the live inputs of a scan sequence.  What stays modelled (GL leaves it to the driver): triangle coverage of K4,
+ * transcendental last bits, blend order; see the deviation tests in that file.  Each function cites the
+ * file:line it follows; analytic known-answer tests are in tests/test_oracle_kat.py.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  * The product (semantic_suma_amd/) never links, imports or calls it.
@@ -74,6 +77,15 @@ const uint8_t* ora_map_integrated(const ora_ctx* c);       /* P */
 uint32_t ora_map_last_updated_count(const ora_ctx* c);     /* S' */
 uint32_t ora_map_last_new_count(const ora_ctx* c);         /* D  */
 uint32_t ora_map_cached_surfels(const ora_ctx* c);         /* surfels parked in submap caches */
+const suma_surfel* ora_map_updated_surfels(const ora_ctx* c); /* K9 output (S' records), before K11 */
+const suma_surfel* ora_map_data_surfels(const ora_ctx* c);    /* K10 output (D records), before K11 */
+const float* ora_map_poses(const ora_ctx* c);                 /* pose table, max_poses x 16 */
+uint32_t ora_map_pending_extractions(const ora_ctx* c);
+const suma_surfel* ora_map_cache_tile(const ora_ctx* c, int32_t i, int32_t j, uint32_t* n);
+uint32_t ora_map_last_extraction(const ora_ctx* c, int32_t* ij); /* returns the number of K12 extractions so far */
+/* K4 vertex + geometry stage per surfel, before rasterisation (tests/test_ref_shaders.py) */
+void ora_debug_render_quads(const ora_ctx* c, const float pose[16], float conf_threshold, int mode, int32_t thr,
+                            uint8_t* emitted, float* corners, float* pn);
 void ora_map_submap_origin(const ora_ctx* c, int32_t* ij);
 
 /* SurfelMapping::processScan (src/core/SurfelMapping.cpp:175-210) without loop closures */

@@ -58,14 +58,18 @@ static void derive(suma_ctx* c) {
   c->pm.H = (int32_t)p.model_height;
   float vfov = fabsf(p.data_fov_up) + fabsf(p.data_fov_down);
   float hfov = 360.0f;
-  float vpix = (float)tan((double)(0.5f * deg2rad_f(vfov) / (float)p.data_height));
-  float hpix = (float)tan((double)(0.5f * deg2rad_f(hfov) / (float)p.data_width));
+  /* SurfelMap.cpp:342-343: 0.5f * Math::deg2rad(vfov) / uint32_t(height) -- rv::Math::deg2rad is double -> the
+   * whole argument is evaluated in double (Math.h:44-47), std::tan(double), then rounded to float */
+  float vpix = (float)tan(0.5 * ((double)vfov * M_PI / 180.0) / (double)p.data_height);
+  float hpix = (float)tan(0.5 * ((double)hfov * M_PI / 180.0) / (double)p.data_width);
   c->mc.pixel_size = vpix < hpix ? hpix : vpix;
   c->mc.p_unstable = 1.0f - p.p_stable;
   c->mc.log_prior = (float)log((double)p.p_prior / (1.0 - (double)p.p_prior));
   c->mc.log_unstable = (float)log((double)c->mc.p_unstable / (1.0 - (double)c->mc.p_unstable));
   c->mc.radconf_angle_thresh = (float)cos((double)deg2rad_f(p.max_angle));
-  c->mc.update_angle_thresh = (float)sin((double)deg2rad_f(p.map_max_angle));
+  /* SurfelMap.cpp:407: std::sin(Radians(float)) -- rv/geometry.h:81-84 Radians() is ((float)M_PI / 180.f) * deg in
+   * float, and std::sin(float) is sinf */
+  c->mc.update_angle_thresh = sinf(((float)M_PI / 180.f) * p.map_max_angle);
 }
 
 #define CK(expr)                                                                 \
@@ -1175,7 +1179,7 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   float t_err = (float)sqrt((delta[12] * delta[12] + delta[13] * delta[13]) + delta[14] * delta[14]);
   float angle = (float)(0.5 * (((delta[0] + delta[5]) + delta[10]) - 1.0));
   float r_err = (float)acos((double)fmaxf(fminf(angle, 1.0f), -1.0f));
-  const bool fallback = (s->timestamp > 1 && (t_err > 0.4f || r_err > 0.1f) && c->p.fallback_mode); /* :438-449 */
+  const bool fallback = (s->timestamp > 1 && ((double)t_err > 0.4 || (double)r_err > 0.1) && c->p.fallback_mode); /* :438-449: float against the double literals */
   if (fallback) {
     s->track_loss += 1;
     suma_params saved = c->p;

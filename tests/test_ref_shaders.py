@@ -1,0 +1,330 @@
+"""oracle/ pinned to the reference's own source text.
+
+oracle/_ref/libsuma_ref.so is the reference's GLSL (src/shader/*.vert|.geom|.frag) and src/core/lie_algebra.cpp
+compiled with g++ where they lie (oracle/ref_build.py + oracle/glsl_compat.hpp + oracle/ref_driver.cpp).  These
+tests feed IDENTICAL inputs to the compiled reference shaders and to the CPU restatement in oracle/*.c -- stage by
+stage, "teacher forced" along a scan sequence, so every stage sees the real inputs of a running pipeline -- and
+demand equal values on every float, integer, label and branch decision.  (Equal values: +0 == -0; the oracle adds
+the w = 0 column of a direction transform nowhere, the shader adds `col3 * 0`.)
+
+Tolerances appear only where the two sides do not run the same operations by construction, each with its size
+measured here: glibc vs include/suma_detmath.h transcendentals (the libm builds), Eigen's evaluation order
+(SE3::exp), and the documented deviations of the oracle from GL / Eigen behaviour (slerp of identical normals,
+general vs rigid matrix inverse, unpivoted LDL^T, fp32 blending vs exact sums, upper-triangle J^T J,
+float-vs-double fallback threshold).
+
+CPU only; skipped when oracle/_ref is not built (it is built in the authoring container and travels with the tree).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import pyref
+from semantic_suma_amd.types import ACC_SCALE, params_with_size
+
+pytestmark = pytest.mark.skipif(not pyref.available(), reason="oracle/_ref not built (needs /root/reference)")
+
+W, H, N_SCANS = 360, 32, 14
+
+
+def eq(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, f"{what}: shape {a.shape} vs {b.shape}"
+    both_nan = np.isnan(a) & np.isnan(b) if a.dtype.kind == "f" else np.zeros(a.shape, bool)
+    ne = (a != b) & ~both_nan
+    n = int(np.count_nonzero(ne))
+    assert n == 0, f"{what}: {n} of {ne.size} values differ; first at {np.argwhere(ne)[:4].tolist()}: " \
+                   f"{a[ne][:4]} vs {b[ne][:4]}"
+
+
+def eq_surfels(a, b, what):
+    assert a.shape == b.shape, f"{what}: {a.shape[0]} vs {b.shape[0]} surfels"
+    for name in a.dtype.names:
+        eq(a[name], b[name], f"{what}.{name}")
+
+
+def conf_threshold(p, t):
+    """SurfelMapping::getConfidenceThreshold, SurfelMapping.cpp:333-340 (as oracle/o_pipeline.c)"""
+    f = np.float32
+    ct = f(p.confidence_threshold)
+    if t < 10:
+        pu = f(0.1)
+        log_unstable = f(math.log(float(pu / (f(1.0) - pu))))
+        alpha = f(t) / f(10)
+        ct = f((1.0 - float(alpha)) * float(log_unstable) + float(alpha * f(p.confidence_threshold)))
+    return float(ct)
+
+
+@pytest.fixture(scope="module")
+def sequence(oracle_lib, scans):
+    """One oracle pipeline run, every stage checked against the compiled reference shaders on the way."""
+    p = params_with_size(W, H, max_surfels=1 << 19)
+    pipe = oracle_lib.OraclePipeline(p)
+    ref = pyref.Ref(p)
+    log = {"scans": 0, "k9_integrated": 0, "k9_dropped": 0, "quads": 0, "extractions": 0, "origin_shifts": 0, "slerp_nan": 0}
+    ora = pipe.ctx
+    for t in range(N_SCANS):
+        pts, lab, prob, _ = scans(t, W, True, H)
+        before = ora.map_surfels()
+        origin_before = ora.map_submap_origin()
+        pending_before = ora.map_pending_extractions()
+        n_extr_before, _ = ora.map_last_extraction()
+        pipe.process_scan(pts, lab, prob, fixed_iterations=5)
+
+        # ---- K1-K3  Preprocessing::process
+        cur = pipe.frame(0)
+        v, n, s = ref.preprocess(pts, lab, prob, t)
+        eq(v, cur.vertex, f"scan {t} K1 vertex map")
+        eq(n, cur.normal, f"scan {t} K2 normal map")
+        eq(s, cur.semantic, f"scan {t} K3 semantic map")
+        frame = (cur.vertex.copy(), cur.normal.copy(), cur.semantic.copy())
+
+        # ---- SurfelMap::update(pose, frame): K7, K8, K9, K10, K11, K12
+        poses = ora.map_poses(t + 2)
+        pose = poses[t].reshape(4, 4).T  # poses_[timestamp_] = pose, SurfelMap.cpp:494
+        idx = ref.indexmap(before, poses, pose)
+        eq(idx, ora.map_index_map().astype(np.float32), f"scan {t} K7 index map")
+        rc = ref.radius_conf(frame[0], frame[1])
+        eq(rc, ora.map_radius_conf(), f"scan {t} K8 radius/confidence map")
+        # every stage below takes the ORACLE's outputs of the stages before it as its inputs (teacher forcing)
+        o_idx, o_rc = ora.map_index_map().astype(np.float32), ora.map_radius_conf()
+        upd, mask = ref.update(before, poses, pose, t, frame, o_rc, o_idx)
+        o_upd = ora.map_updated_surfels()
+        # documented deviation (update_surfels.vert:113-124): slerp of two identical normals is 0 * inf = NaN in
+        # GLSL and poisons the surfel's normal; the oracle keeps the old normal.  Those records are exempt in nx/ny/nz.
+        nan_normal = np.isnan(upd["nx"]) & np.isnan(upd["ny"]) & np.isnan(upd["nz"])
+        assert upd.shape == o_upd.shape, f"scan {t} K9 count {upd.shape[0]} vs {o_upd.shape[0]}"
+        assert np.all(np.isfinite(o_upd["nx"][nan_normal])) and nan_normal.sum() <= 0.002 * max(1, upd.shape[0])
+        for name in ("nx", "ny", "nz"):
+            upd[name][nan_normal] = o_upd[name][nan_normal]
+        eq_surfels(upd, o_upd, f"scan {t} K9 updated surfels")
+        o_mask = ora.map_integrated() != 0
+        eq(mask[:, :, 0] > 0.5, o_mask, f"scan {t} K9 integration mask")
+        eq(mask[:, :, 1:], np.zeros_like(mask[:, :, 1:]), "K9 mask colour (1,0,0,0)")
+        o_mask4 = np.zeros((H, W, 4), np.float32)
+        o_mask4[:, :, 0] = o_mask
+        gen = ref.generate(frame, o_rc, o_mask4, pose, t)
+        o_gen = ora.map_data_surfels()
+        eq_surfels(gen, o_gen, f"scan {t} K10 new surfels")
+        ext = np.float32(2.0) * np.float32(p.submap_dimension) * np.float32(p.submap_extent) + np.float32(p.submap_extent)
+        if p.partial_extraction and pending_before > 0:
+            ext = ext + np.float32(2.0) * np.float32(p.submap_extent)  # SurfelMap.cpp:674-677
+        center = (np.float32(2.0 * origin_before[0] * p.submap_extent), np.float32(2.0 * origin_before[1] * p.submap_extent))
+        copied = ref.copy(o_upd, o_gen, poses, center, ext)
+        after = ora.map_surfels()
+        eq_surfels(copied, after[: copied.shape[0]], f"scan {t} K11 active-area copy")
+        log["slerp_nan"] += int(nan_normal.sum())
+        log["k9_integrated"] += int(np.count_nonzero(mask[:, :, 0]))
+        log["k9_dropped"] += before.shape[0] - upd.shape[0]
+        if ora.map_submap_origin() != origin_before:
+            log["origin_shifts"] += 1
+        n_extr, (ei, ej) = ora.map_last_extraction()
+        if n_extr != n_extr_before:  # one tile extracted from the post-copy map (K12)
+            c = (np.float32(2.0 * ei * p.submap_extent), np.float32(2.0 * ej * p.submap_extent))
+            tile = ref.extract(after, poses, c, p.submap_extent)
+            eq_surfels(tile, ora.map_cache_tile(ei, ej), f"scan {t} K12 extracted tile ({ei},{ej})")
+            log["extractions"] += 1
+
+        # ---- SurfelMap::render(pose, pose, ct) after the update: K4 vertex + geometry stage, K5
+        ct = conf_threshold(p, t)
+        thr = int(ora.map_timestamp()) - 100  # SurfelMap.cpp:873, quirk B-7: negative for the first 100 scans
+        for mode, render_old in ((0, True), (1, False)):
+            emitted, corners, pn = ora.debug_render_quads(pose, ct, mode, thr)
+            r_emit, r_pos, r_tex, r_attr = ref.render_quads(after, poses, pose, ct, render_old, thr)
+            eq(r_emit == 4, emitted == 1, f"scan {t} K4 gate (old={render_old})")
+            assert set(np.unique(r_emit)) <= {0, 4}
+            m = emitted == 1
+            # gl_Position = vec4(2 * project2model(..) - 1, 1), render_surfels.geom:104-116
+            ndc = np.float32(2.0) * corners[m] - np.float32(1.0)
+            eq(r_pos[m][:, :, :3], ndc, f"scan {t} K4 strip corners (old={render_old})")
+            eq(r_pos[m][:, :, 3], np.ones_like(ndc[:, :, 0]), "K4 gl_Position.w")
+            eq(r_tex[m], np.broadcast_to(np.array([[-1, -1], [1, -1], [-1, 1], [1, 1]], np.float32), r_tex[m].shape), "K4 texCoords")
+            eq(r_attr[m][:, 0:3], pn[m][:, 0:3], "K4 vertex output")
+            eq(r_attr[m][:, 4:7], pn[m][:, 3:6], "K4 normal output")
+            sem = np.stack([after[k] for k in ("r", "g", "b", "w")], axis=1)
+            eq(r_attr[m][:, 8:12], sem[m], "K4 semantic output")
+            log["quads"] += int(np.count_nonzero(m))
+        old_f, new_f = ora.map_frame(0), ora.map_frame(1)
+        comp = ref.compose((old_f.vertex, old_f.normal, old_f.semantic), (new_f.vertex, new_f.normal, new_f.semantic))
+        model = pipe.frame(2)
+        eq(comp[0], model.vertex, f"scan {t} K5 composed vertex map")
+        eq(comp[1], model.normal, f"scan {t} K5 composed normal map")
+        eq(comp[2], model.semantic, f"scan {t} K5 composed semantic map")
+        log["scans"] += 1
+    return {"pipe": pipe, "ref": ref, "params": p, "log": log, "oracle_lib": oracle_lib}
+
+
+def test_every_stage_along_a_sequence(sequence):
+    """K1-K5, K7-K12 on the live inputs of a 14-scan run (the fixture asserts); here: the run was not vacuous."""
+    log = sequence["log"]
+    assert log["scans"] == N_SCANS
+    assert log["k9_integrated"] > 5000 and log["k9_dropped"] > 100 and log["quads"] > 20000
+    assert log["origin_shifts"] >= 1 and log["extractions"] >= 1, log
+
+
+def unpack_fix(fix48):
+    """2 x 8 RGB blend target (Frame2Model_jacobians.geom:47-51; unpacked at Frame2Model.cpp:214-227) -> the
+    oracle's 32 accumulator words (oracle/o_icp.c)"""
+    t = fix48.reshape(8, 2, 3)
+    full = np.zeros((6, 6), dtype=np.int64)
+    for i in range(6):
+        full[i, 0:3] = t[i, 0]
+        full[i, 3:6] = t[i, 1]
+    acc = np.zeros(32, dtype=np.int64)
+    k = 0
+    for i in range(6):
+        for j in range(i, 6):
+            acc[k] = full[i, j]
+            k += 1
+    acc[21:24] = t[6, 0]
+    acc[24:27] = t[6, 1]
+    acc[27] = t[7, 0, 1]
+    acc[28] = t[7, 1, 0]
+    sc = int(ACC_SCALE)
+    for w, val in ((29, t[7, 0, 0]), (30, t[7, 0, 2]), (31, t[7, 1, 1])):
+        assert val % sc == 0
+        acc[w] = val // sc
+    return acc, full
+
+
+@pytest.mark.parametrize("weight_function,bilinear", [(1, 1), (2, 1), (0, 1), (1, 0)])
+def test_k6_per_pixel_terms(sequence, weight_function, bilinear):
+    """Frame2Model_jacobians.geom:83-200 with one entry per geometry-shader invocation: every per-pixel term the
+    shader emits, converted to the oracle's 2^-28 fixed point and summed exactly, equals the oracle's words."""
+    pipe, oracle_lib = sequence["pipe"], sequence["oracle_lib"]
+    p = params_with_size(W, H, weight_function=weight_function, bilinear_sampling=bilinear, factor=0.25)
+    ora, ref = oracle_lib.Oracle(p), pyref.Ref(p)
+    cur, model = pipe.frame(0), pipe.frame(2)
+    curm, modelm = (cur.vertex, cur.normal, cur.semantic), (model.vertex, model.normal, model.semantic)
+    T = np.eye(4)
+    c, s = math.cos(0.004), math.sin(0.004)
+    T[:2, :2] = [[c, -s], [s, c]]
+    T[:3, 3] = [0.9, -0.05, 0.01]
+    for iteration in (0, 1):
+        _, acc, _, _, st = ora.jacobian_products(cur, model, T, iteration)
+        blend, fix = ref.jacobians(curm, modelm, T, iteration, entries_per_kernel=1)
+        racc, full = unpack_fix(fix)
+        eq(racc, acc, f"K6 accumulator words (weight {weight_function}, bilinear {bilinear}, iteration {iteration})")
+        assert st.valid > 1500 and st.outlier > 0 and st.invalid > 0
+        # deviation "J^T J from the upper triangle": the shader also forms the lower triangle as (w J_i) J_j with
+        # the factors swapped; it differs from the mirrored upper triangle by rounding only
+        asym = np.abs(full - full.T).max() / ACC_SCALE
+        assert asym < 1e-2 * max(1.0, np.abs(full).max() / ACC_SCALE * 1e-4), asym
+        # deviation "exact sums": the reference adds 64 entries per invocation in fp32 and blends the invocations in
+        # fp32 (Frame2Model.cpp:189-190); the exact sums agree with that to fp32 accumulation error
+        blend64, _ = ref.jacobians(curm, modelm, T, iteration, entries_per_kernel=64)
+        exact = fix.astype(np.float64) / ACC_SCALE
+        scale = np.abs(exact).max()
+        assert np.abs(blend64.astype(np.float64) - exact).max() < 2e-5 * scale
+
+
+def test_k6_nearest_and_gates(sequence):
+    """the fallback objective's gates (SurfelMapping.cpp:87-94) through the same shader"""
+    pipe, oracle_lib = sequence["pipe"], sequence["oracle_lib"]
+    p = params_with_size(W, H, icp_max_distance=0.5, icp_max_angle=30.0)
+    ora, ref = oracle_lib.Oracle(p), pyref.Ref(p)
+    cur, model = pipe.frame(0), pipe.frame(2)
+    T = np.eye(4)
+    T[0, 3] = 1.3
+    _, acc, _, _, st = ora.jacobian_products(cur, model, T, 0)
+    _, fix = ref.jacobians((cur.vertex, cur.normal, cur.semantic), (model.vertex, model.normal, model.semantic), T, 0, 1)
+    eq(unpack_fix(fix)[0], acc, "K6 with fallback gates")
+    assert st.outlier > 100
+
+
+def test_se3_exp_and_log():
+    """src/core/lie_algebra.cpp compiled where it lies (against oracle/eigen_shim) vs oracle/o_icp.c.  Not bit for
+    bit by construction: glibc sin/cos vs suma_detmath's, and Eigen-shim product order; size: <= 4 ulp of double."""
+    from oracle import pyoracle
+    rng = np.random.default_rng(3)
+    worst = 0.0
+    for k in range(200):
+        x = rng.normal(size=6) * (10.0 ** rng.uniform(-6, 0))
+        if k % 10 == 0:
+            x[3:] = 0.0  # theta <= 1e-10 branch
+        a, b = pyref.se3_exp(x), pyoracle.se3_exp(x)
+        err = np.abs(a - b).max() / max(1.0, np.abs(a).max())
+        worst = max(worst, err)
+        if np.linalg.norm(x[3:]) > 1e-3:  # SE3::log drops rotations with 1 - cos(theta) < 1e-10 (lie_algebra.cpp:46)
+            back = pyref.se3_log(a)
+            assert np.abs(back - x).max() < 1e-7 * max(1.0, np.abs(x).max())
+    assert worst < 1e-15, worst
+
+
+def test_deviation_slerp_of_identical_normals():
+    """update_surfels.vert:113-124: slerp(v, v, w) = (sin(w*0)/sin 0) v + ... = NaN in GLSL.  The oracle (and the HIP
+    kernels) return v0 instead (documented deviation): a GL driver would poison the surfel with NaN."""
+    v = np.array([0.0, 0.6, 0.8], np.float32)
+    out = pyref.glsl_slerp(v, v, 0.9)
+    assert np.all(np.isnan(out)), out
+    a = np.array([0.0, 0.6, 0.8], np.float32)
+    b = np.array([0.1, 0.6, 0.79], np.float32)
+    r = pyref.glsl_slerp(a, b, 0.9)
+    assert np.all(np.isfinite(r)) and abs(np.linalg.norm(r) - np.linalg.norm(a)) < 1e-2
+
+
+def test_deviation_matrix_inverse():
+    """update_surfels.vert:197 inverse(surfelPose) and Eigen's pose.inverse() (SurfelMap.cpp:497) are general 4x4
+    inverses in fp32; the oracle uses R^T, -R^T t evaluated in double.  Size of the difference on rigid poses."""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for _ in range(200):
+        w = rng.normal(size=3)
+        w *= rng.uniform(0, 3.0) / np.linalg.norm(w)
+        K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        th = np.linalg.norm(w)
+        R = np.eye(3) + math.sin(th) / th * K + (1 - math.cos(th)) / th ** 2 * K @ K
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = rng.uniform(-500, 500, size=3)
+        Tf = T.astype(np.float32)
+        a = pyref.glsl_inverse(Tf).astype(np.float64)
+        b = pyref.rigid_inverse_f32(Tf).astype(np.float64)
+        worst = max(worst, np.abs(a[:3, :3] - b[:3, :3]).max(), np.abs(a[:3, 3] - b[:3, 3]).max() / 500.0)
+        exact = np.linalg.inv(Tf.astype(np.float64))
+        assert np.abs(b - exact).max() <= np.abs(a - exact).max() + 1e-4  # the rigid form is the closer one
+    assert worst < 5e-6, worst
+
+
+def test_deviation_unpivoted_ldlt(oracle_lib):
+    """LieGaussNewton.cpp:60 JtJ.ldlt().solve(-Jtf): Eigen pivots, the oracle / kernels do not (Eigen is not in the
+    tree).  On SPD systems of this problem's shape both agree with a pivoted LU solve to fp64 conditioning."""
+    rng = np.random.default_rng(11)
+    for _ in range(50):
+        J = rng.normal(size=(400, 6)) * np.array([1, 1, 1, 30, 30, 30])
+        A = J.T @ J
+        b = J.T @ rng.normal(size=400)
+        x = oracle_lib.solve6(A, b)
+        xr = np.linalg.solve(A, -b)
+        assert np.abs(x - xr).max() <= 1e-10 * max(1.0, np.abs(xr).max())
+
+
+def test_deviation_fallback_threshold_is_a_double_compare():
+    """SurfelMapping.cpp:438 compares float t_err / r_err with the double literals 0.4 / 0.1 (fixed in round 2: the
+    oracle and the product used 0.4f / 0.1f): a float equal to 0.4f IS greater than 0.4."""
+    assert float(np.float32(0.4)) > 0.4 and float(np.float32(0.1)) > 0.1
+
+
+def test_libm_build_agrees_to_tolerance(sequence, scans):
+    """Same shaders with glibc's transcendentals (libsuma_ref_libm.so) against the detmath oracle: the size of
+    "GL leaves atan / asin / exp / log to the driver".  A few pixels move to a neighbouring texel, nothing else."""
+    if not pyref.available("libm"):
+        pytest.skip("libm variant not built")
+    p = sequence["params"]
+    pipe = sequence["pipe"]
+    refm = pyref.Ref(p, "libm")
+    pts, lab, prob, _ = scans(N_SCANS - 1, W, True, H)
+    v, n, s = refm.preprocess(pts, lab, prob, N_SCANS - 1)
+    cur = pipe.frame(0)
+    moved = np.count_nonzero(np.any(v != cur.vertex, axis=2))
+    assert moved <= 0.002 * W * H, moved
+    model = pipe.frame(2)
+    T = np.eye(4)
+    T[0, 3] = 1.0
+    _, acc, _, _, _ = pipe.ctx.jacobian_products(cur, model, T, 0)
+    _, fix = refm.jacobians((cur.vertex, cur.normal, cur.semantic), (model.vertex, model.normal, model.semantic), T, 0, 1)
+    racc, _ = unpack_fix(fix)
+    assert abs(int(racc[29]) - int(acc[29])) <= 0.002 * acc[29]
+    big = np.abs(acc[:27]) > 0.01 * np.abs(acc[:27]).max()
+    assert np.all(np.abs(racc[:27][big] - acc[:27][big]) <= 3e-3 * np.abs(acc[:27][big]))
