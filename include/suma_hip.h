@@ -68,6 +68,15 @@ uint32_t suma_frame_width(const suma_frame* f);
 uint32_t suma_frame_height(const suma_frame* f);
 /* device address of one map (HIP->GL interop / zero-copy consumers) */
 void* suma_frame_device_ptr(const suma_frame* f, int which);
+/* exchange the contents of two frames of equal size (the shared_ptr swaps of SurfelMapping::initialize,
+ * SurfelMapping.cpp:323-331): O(1), no copy */
+int suma_frame_swap(suma_ctx* ctx, suma_frame* a, suma_frame* b);
+/* viewer feed (ViewportWidget.cpp:404-434 binds Frame::vertex_map / normal_map / semantic_map as textures): the
+ * device buffer of one map with its layout -- row-major, row 0 = lowest beam, RGBA32F texels, row_bytes = 16 * width.
+ * The pointer stays valid for the life of the frame; contents change with the next call that writes the frame.
+ * INTEGRATION.md shows the hipGraphicsGLRegisterImage / hipMemcpy2DToArrayAsync recipe. */
+int suma_frame_export(suma_ctx* ctx, const suma_frame* f, int which, void** d_ptr, uint32_t* width, uint32_t* height,
+                      uint32_t* row_bytes);
 
 /* ---- Preprocessing::process (Preprocessing.h:55-56, Preprocessing.cpp:120-339): K1 z-buffered
  *      spherical scatter, K2 cross-stencil normals + label erosion, K3 label flood fill.
@@ -80,6 +89,18 @@ int suma_preprocess_device(suma_ctx* ctx, const suma_float4* d_points, const flo
 
 /* ---- Objective::setData (Objective.h:58, Frame2Model.cpp:117-123) */
 int suma_icp_set_data(suma_ctx* ctx, const suma_frame* current, const suma_frame* model);
+/* ---- the parameters a Frame2Model OBJECT owns (Frame2Model::updateParameters / setParameter, Frame2Model.cpp:65-115).
+ *      The reference builds two objectives with different gates -- objective_ and recovery_ = Frame2Model(fallback
+ *      parameters), SurfelMapping.cpp:87-94 -- while one suma_ctx carries one parameter block.  An adapter object
+ *      sends its own values before each launch; NULL returns to the ctx parameters (suma_params). */
+typedef struct suma_icp_objective {
+  float icp_max_distance; /* "icp-max-distance" */
+  float icp_max_angle;    /* "icp-max-angle", degrees */
+  int32_t weight_function; /* SUMA_WEIGHT_* ("weighting") */
+  float factor;
+  int32_t bilinear_sampling;
+} suma_icp_objective;
+int suma_icp_set_objective(suma_ctx* ctx, const suma_icp_objective* objective);
 /* ---- Frame2Model::jacobianProducts (Frame2Model.h:50, Frame2Model.cpp:136-261): K6 at the given
  *      pose.  JtJ 6x6 column-major, Jtr 6; acc (optional) = the raw 2^-28 fixed-point sums,
  *      SUMA_ACC_WORDS int64.  Returns F in stats->error. */
@@ -91,6 +112,9 @@ int suma_icp_jacobian_products(suma_ctx* ctx, const double pose[16], uint32_t it
  *      history (optional): history_cap x 16 doubles receive LieGaussNewton::history(); *n_hist = entries pushed. */
 int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], double* history, uint32_t history_cap,
                       uint32_t* n_hist, suma_icp_stats* stats);
+/* LieGaussNewton::information() (LieGaussNewton.h:50, LieGaussNewton.cpp:75,103-105): J^T W J of the last step of the
+ * last suma_icp_minimize (or of the last suma_icp_jacobian_products), 6x6 column-major */
+int suma_icp_information(suma_ctx* ctx, double information[36]);
 /* n_hyp independent minimisations of the same frame pair from different T0 (the reference's
  * loop-closure verification pattern, SurfelMapping.cpp:662-779; BASELINE config 3) in one batch. */
 int suma_icp_minimize_batch(suma_ctx* ctx, const double* T0s, uint32_t n_hyp, double* T_out, suma_icp_stats* stats);
@@ -112,6 +136,15 @@ int suma_map_size(suma_ctx* ctx, uint32_t* n);                              /* S
 int suma_map_timestamp(suma_ctx* ctx, uint32_t* t);
 /* getAllSurfels(), SurfelMap.cpp:1232-1237: copies min(size, cap) surfels; *n = size */
 int suma_map_download(suma_ctx* ctx, suma_surfel* host, uint32_t cap, uint32_t* n);
+/* viewer feed / getModelSurfels() / getDataSurfels() (SurfelMap.h:64-67; SurfelMap::draw reads the surfel VBO,
+ * SurfelMap.cpp:1167-1230): the device buffer of the active map, *n records of 64 bytes in the layout of
+ * suma_surfel (= the reference's Surfel / its VAO layout, SurfelMap.cpp:46-55).  The map is double buffered: the
+ * pointer is valid (and its contents stable) until the next suma_map_update / suma_map_upload / suma_map_reset or
+ * pipeline scan.  The data surfels of the last update are the tail [*first, *first + *n_data) of the same buffer:
+ * the new surfels that survived the active-area copy (the reference's data_surfels_ also holds the ones K11
+ * dropped).  INTEGRATION.md shows the hipGraphicsGLRegisterBuffer recipe. */
+int suma_map_export_surfels(suma_ctx* ctx, void** d_ptr, uint32_t* n);
+int suma_map_export_data_surfels(suma_ctx* ctx, void** d_ptr, uint32_t* first, uint32_t* n_data);
 /* checkpoint / resume: replace the active map */
 int suma_map_upload(suma_ctx* ctx, const suma_surfel* host, uint32_t n, uint32_t timestamp);
 /* intermediates of the last update, for stage-by-stage parity tests */
@@ -131,6 +164,19 @@ int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, cons
                                uint32_t n, int32_t fixed_iterations);
 int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
                                       const float* d_probs, uint32_t n, int32_t fixed_iterations);
+/* ---- device-side scan ingest (KITTIReader::read hands over host vectors, KITTIReader.cpp:136-203 ->
+ *      SurfelMapping::processScan(const rv::Laserscan&), SurfelMapping.cpp:175): two pinned staging slots, a copy
+ *      stream and an ingest thread.  prefetch stages the scan (host copy into pinned memory + async H2D, both off
+ *      the caller's thread) and returns at once; process_prefetched runs the oldest staged scan, its first kernel
+ *      waiting on the upload's event.  Calling prefetch(scan k+1) before process_prefetched(scan k) overlaps the
+ *      upload of k+1 with the kernels of k.  At most two scans may be staged; the host arrays must stay valid
+ *      until the matching process call returns.  suma_pipeline_process_scan_async = prefetch (unless that very
+ *      scan is already staged) + process_prefetched. */
+int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                                uint32_t n);
+int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_iterations);
+int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_float4* points, const float* labels,
+                                     const float* probs, uint32_t n, int32_t fixed_iterations);
 int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
 int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
 int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);
@@ -166,6 +212,7 @@ int suma_loop_closure_verify(suma_ctx* ctx, const suma_frame* current, const dou
 int suma_device_alloc(suma_ctx* ctx, uint64_t bytes, void** d_ptr);
 int suma_device_free(suma_ctx* ctx, void* d_ptr);
 int suma_device_upload(suma_ctx* ctx, void* d_dst, const void* host_src, uint64_t bytes);
+int suma_device_download(suma_ctx* ctx, void* host_dst, const void* d_src, uint64_t bytes);
 
 /* ---- per-kernel timing (rv::Stopwatch / SurfelMapping::Stats, SurfelMapping.cpp:183-207):
  *      on = 1: every kernel group is bracketed by HIP events on the ctx stream; on = 2: only the

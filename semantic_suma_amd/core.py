@@ -41,6 +41,12 @@ class LoopResult(C.Structure):
                 ("pose_old", C.c_float * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
 
 
+class IcpObjective(C.Structure):
+    """suma_icp_objective (include/suma_hip.h): the parameters one Frame2Model object owns"""
+    _fields_ = [("icp_max_distance", C.c_float), ("icp_max_angle", C.c_float), ("weight_function", C.c_int32),
+                ("factor", C.c_float), ("bilinear_sampling", C.c_int32)]
+
+
 class KernelTime(C.Structure):
     _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double), ("bytes", C.c_double)]
 
@@ -78,6 +84,16 @@ def lib():
     L.suma_frame_height.argtypes = [vp]
     L.suma_frame_device_ptr.restype = vp
     L.suma_frame_device_ptr.argtypes = [vp, C.c_int]
+    L.suma_frame_swap.argtypes = [vp, vp, vp]
+    L.suma_frame_export.argtypes = [vp, vp, C.c_int, pp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.suma_icp_set_objective.argtypes = [vp, C.POINTER(IcpObjective)]
+    L.suma_icp_information.argtypes = [vp, vp]
+    L.suma_map_export_surfels.argtypes = [vp, pp, C.POINTER(u32)]
+    L.suma_map_export_data_surfels.argtypes = [vp, pp, C.POINTER(u32), C.POINTER(u32)]
+    L.suma_pipeline_prefetch_scan.argtypes = [vp, vp, vp, vp, u32]
+    L.suma_pipeline_process_prefetched.argtypes = [vp, i32]
+    L.suma_pipeline_process_scan_async.argtypes = [vp, vp, vp, vp, u32, i32]
+    L.suma_device_download.argtypes = [vp, vp, vp, C.c_uint64]
     L.suma_preprocess.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.suma_preprocess_device.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     L.suma_icp_set_data.argtypes = [vp, vp, vp]
@@ -176,6 +192,12 @@ class Context:
         self.check(self.L.suma_device_upload(self.h, p, _ptr(host), host.nbytes), "suma_device_upload")
         return p.value
 
+    def device_download(self, d_ptr: int, nbytes: int) -> np.ndarray:
+        """copy `nbytes` from a device address (e.g. an exported viewer buffer) to the host"""
+        out = np.empty(nbytes, dtype=np.uint8)
+        self.check(self.L.suma_device_download(self.h, _ptr(out), C.c_void_p(d_ptr), nbytes), "suma_device_download")
+        return out
+
     def device_free(self, p: int):
         self.check(self.L.suma_device_free(self.h, C.c_void_p(p)), "suma_device_free")
 
@@ -245,6 +267,17 @@ class Frame:
     def semantic(self):
         return self.download(2)
 
+    def swap(self, other: "Frame"):
+        """exchange contents with `other` (the shared_ptr swaps of SurfelMapping.cpp:323-331), O(1)"""
+        self.ctx.check(self.ctx.L.suma_frame_swap(self.ctx.h, self.h, other.h), "suma_frame_swap")
+
+    def export(self, which: int):
+        """viewer feed: (device address, width, height, row_bytes) of one map"""
+        p, w, h, rb = C.c_void_p(), C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_frame_export(self.ctx.h, self.h, which, C.byref(p), C.byref(w), C.byref(h),
+                                                    C.byref(rb)), "suma_frame_export")
+        return p.value, w.value, h.value, rb.value
+
     def copy(self, other: "Frame"):
         """Frame::copy (Frame.h:49-61)"""
         self.ctx.check(self.ctx.L.suma_frame_copy(self.ctx.h, self.h, other.h), "suma_frame_copy")
@@ -275,20 +308,47 @@ class Preprocessing:
 
 
 class Frame2Model:
-    """Objective.h:14-82 as implemented by Frame2Model.h:28-73."""
-    num_parameters = 6
+    """Objective.h:14-82 as implemented by Frame2Model.h:28-73.
 
-    def __init__(self, ctx: Context):
+    Like the reference's object, an instance owns its parameters (icp-max-distance, icp-max-angle, weighting,
+    factor, bilinear_sampling; Frame2Model::updateParameters, Frame2Model.cpp:65-110) and its frame pair, and sends
+    both to the device before every launch -- two instances with different gates on one Context (objective_ and
+    recovery_ = Frame2Model(fallback_params), SurfelMapping.cpp:87-94) do not disturb each other."""
+    num_parameters = 6
+    _PARAM_NAMES = {"icp-max-distance": "icp_max_distance", "icp-max-angle": "icp_max_angle", "factor": "factor",
+                    "bilinear_sampling": "bilinear_sampling"}
+    _WEIGHTING = {"none": 0, "huber": 1, "turkey": 2, "stability": 3}
+
+    def __init__(self, ctx: Context, params: SumaParams = None):
         self.ctx = ctx
+        p = ctx.params if params is None else params
+        self.objective = IcpObjective(p.icp_max_distance, p.icp_max_angle, p.weight_function, p.factor,
+                                      p.bilinear_sampling)
+        self._current = self._last = None
         self._pose = np.eye(4)
         self._iteration = 0
         self.stats = IcpStats()
         self.acc = np.zeros(ACC_WORDS, dtype=np.int64)
 
+    def setParameter(self, name: str, value):
+        """Objective::setParameter(const rv::Parameter&) -> Frame2Model::setParameter (Frame2Model.cpp:112-115)"""
+        if name == "weighting":
+            self.objective.weight_function = self._WEIGHTING[value]
+        elif name in self._PARAM_NAMES:
+            setattr(self.objective, self._PARAM_NAMES[name], value)
+        # other keys are stored by the reference and never read by this objective
+
     def setData(self, current: Frame, last: Frame):
         self._current, self._last = current, last  # keep alive
-        self.ctx.check(self.ctx.L.suma_icp_set_data(self.ctx.h, current.h, last.h), "suma_icp_set_data")
         self._iteration = 0
+
+    def _bind(self):
+        """this object's frames and parameters become the ones the next launch uses"""
+        if self._current is None:
+            raise SumaError("Frame2Model::setData has not been called")
+        c = self.ctx
+        c.check(c.L.suma_icp_set_data(c.h, self._current.h, self._last.h), "suma_icp_set_data")
+        c.check(c.L.suma_icp_set_objective(c.h, C.byref(self.objective)), "suma_icp_set_objective")
 
     def initialize(self, pose):
         self._pose = np.asarray(pose, dtype=np.float64).copy()
@@ -303,10 +363,16 @@ class Frame2Model:
         Jtr = np.zeros(6, dtype=np.float64)
         pose = _cm(self._pose, np.float64)
         c = self.ctx
+        self._bind()
         c.check(c.L.suma_icp_jacobian_products(c.h, _ptr(pose), self._iteration, _ptr(JtJ), _ptr(Jtr), _ptr(self.acc),
                                                C.byref(self.stats)), "suma_icp_jacobian_products")
         self._iteration += 1
         return self.stats.error, JtJ.T.copy(), Jtr
+
+    def increment(self, delta):
+        """Objective::increment (Objective.h:45-48): pose_ = SE3::exp(delta) * pose_ (host side, numpy)"""
+        self._pose = se3_exp(delta) @ self._pose
+        self._iteration += 1
 
     def inlier(self):
         return self.stats.inlier
@@ -339,6 +405,7 @@ class LieGaussNewton:
         hist = np.zeros((history_cap, 4, 4), dtype=np.float64)
         nh = C.c_uint32(0)
         c = self.ctx
+        objective._bind()
         c.check(c.L.suma_icp_minimize(c.h, _ptr(T0), _ptr(T), _ptr(hist) if history_cap else None, history_cap,
                                       C.byref(nh), C.byref(self.stats)), "suma_icp_minimize")
         self._pose = T.T.copy()
@@ -348,13 +415,15 @@ class LieGaussNewton:
         self._history = hist[:n].transpose(0, 2, 1).copy()
         return 0
 
-    def minimize_batch(self, T0s):
+    def minimize_batch(self, T0s, objective: Frame2Model = None):
         """n_hyp minimisations of the same frame pair (SurfelMapping.cpp:662-779 pattern)"""
         T0s = np.ascontiguousarray(np.asarray(T0s, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
         n = T0s.shape[0]
         out = np.zeros((n, 4, 4), dtype=np.float64)
         stats = (IcpStats * n)()
         c = self.ctx
+        if objective is not None:
+            objective._bind()
         c.check(c.L.suma_icp_minimize_batch(c.h, _ptr(T0s), n, _ptr(out), stats), "suma_icp_minimize_batch")
         return out.transpose(0, 2, 1).copy(), [stats[i].as_dict() for i in range(n)]
 
@@ -366,6 +435,34 @@ class LieGaussNewton:
 
     def iterationCount(self):
         return self.stats.iterations
+
+    def information(self):
+        """LieGaussNewton::information() (LieGaussNewton.cpp:75,103-105): J^T W J of the last step"""
+        out = np.zeros((6, 6), dtype=np.float64)
+        self.ctx.check(self.ctx.L.suma_icp_information(self.ctx.h, _ptr(out)), "suma_icp_information")
+        return out.T.copy()
+
+    @staticmethod
+    def reason(errorno: int) -> str:
+        """LieGaussNewton::reason (LieGaussNewton.cpp:110-115)"""
+        return {-1: "Maximum number of iterations reached.", -2: "Diverging."}.get(errorno, "no error")
+
+
+def se3_exp(x):
+    """SE3::exp (lie_algebra.cpp:4-34) on the host in numpy, for Objective::increment of the mirror classes"""
+    x = np.asarray(x, dtype=np.float64)
+    T = np.eye(4)
+    v, o = x[:3], x[3:]
+    theta = float(np.sqrt(o @ o))
+    if theta > 1e-10:
+        K = np.array([[0, -o[2], o[1]], [o[2], 0, -o[0]], [-o[1], o[0], 0]])
+        K2 = K @ K
+        T[:3, :3] = np.eye(3) + np.sin(theta) / theta * K + (1 - np.cos(theta)) / theta ** 2 * K2
+        V = np.eye(3) + (1 - np.cos(theta)) / theta ** 2 * K + (theta - np.sin(theta)) / theta ** 3 * K2
+        T[:3, 3] = V @ v
+    else:
+        T[:3, 3] = v
+    return T
 
 
 class SurfelMap:
@@ -433,6 +530,21 @@ class SurfelMap:
         self.ctx.check(self.ctx.L.suma_map_download(self.ctx.h, _ptr(out) if n else None, n, C.byref(got)))
         return out
 
+    def getModelSurfels(self):
+        """SurfelMap::getModelSurfels (SurfelMap.h:67) / the VBO SurfelMap::draw reads: (device address, count) of the
+        active map, 64-byte records; valid until the next update / upload / reset"""
+        p, n = C.c_void_p(), C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_export_surfels(self.ctx.h, C.byref(p), C.byref(n)), "suma_map_export_surfels")
+        return p.value, n.value
+
+    def getDataSurfels(self):
+        """SurfelMap::getDataSurfels (SurfelMap.h:64): (device address, first, count) -- the new surfels of the last
+        update that survived the active-area copy, stored as the tail of the active map"""
+        p, f, n = C.c_void_p(), C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_export_data_surfels(self.ctx.h, C.byref(p), C.byref(f), C.byref(n)),
+                       "suma_map_export_data_surfels")
+        return p.value, f.value, n.value
+
     def upload(self, surfels: np.ndarray, timestamp: int):
         surfels = np.ascontiguousarray(surfels, dtype=SURFEL_DTYPE)
         self.ctx.check(self.ctx.L.suma_map_upload(self.ctx.h, _ptr(surfels), surfels.shape[0], timestamp))
@@ -496,6 +608,7 @@ class SurfelMapping:
         self.h = h
         self.ctx = Context(params, handle=C.c_void_p(self.L.suma_pipeline_ctx(h)), owner=self)
         self.map = SurfelMap(self.ctx)
+        self._staged = []
 
     def processScan(self, points, labels=None, probs=None, fixed_iterations: int = 0):
         points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
@@ -510,6 +623,40 @@ class SurfelMapping:
         self.ctx.check(self.L.suma_pipeline_process_scan_device(self.h, C.c_void_p(d_points), C.c_void_p(d_labels),
                                                                 C.c_void_p(d_probs), n, fixed_iterations),
                        "suma_pipeline_process_scan_device")
+
+    def prefetchScan(self, points, labels=None, probs=None):
+        """stage a scan (pinned copy + async upload on the ingest thread / copy stream); the arrays are kept alive
+        until the matching processPrefetched() returns"""
+        points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        probs = None if probs is None else np.ascontiguousarray(probs, dtype=np.float32)
+        self._staged.append((points, labels, probs))
+        self.ctx.check(self.L.suma_pipeline_prefetch_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs),
+                                                          points.shape[0]), "suma_pipeline_prefetch_scan")
+
+    def processPrefetched(self, fixed_iterations: int = 0):
+        self.ctx.check(self.L.suma_pipeline_process_prefetched(self.h, fixed_iterations),
+                       "suma_pipeline_process_prefetched")
+        self._staged.pop(0)
+
+    def processSequence(self, scans, fixed_iterations: int = 0, on_scan=None):
+        """run an iterable of (points, labels, probs) with the upload of scan k+1 overlapping the kernels of scan k
+        (what a reader thread feeding SurfelMapping::processScan does in the reference's visualizer loop)"""
+        it = iter(scans)
+        nxt = next(it, None)
+        if nxt is None:
+            return 0
+        self.prefetchScan(*nxt[:3])
+        k = 0
+        while nxt is not None:
+            nxt = next(it, None)
+            if nxt is not None:
+                self.prefetchScan(*nxt[:3])
+            self.processPrefetched(fixed_iterations)
+            if on_scan is not None:
+                on_scan(k, self)
+            k += 1
+        return k
 
     def getCurrentPose(self):
         T = np.zeros((4, 4), dtype=np.float64)

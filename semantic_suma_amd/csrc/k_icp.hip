@@ -17,15 +17,16 @@
  *   - every fp32 term is converted to 2^-28 fixed point (round to nearest even, via the
  *     1.5*2^52 double trick) and summed as int64: exact and order independent, so the result is
  *     bit-identical for any reduction tree (and to the CPU oracle);
- *   - per-lane int64 accumulators -> wave butterfly (halving exchange, 32 shuffles of 64 bit)
- *     -> LDS across the 8 waves -> one 256-byte partial per block (plain stores);
- *   - no in-kernel hand-off at all: the partials of launch j are consumed by the PROLOGUE of
- *     launch j+1 (kernel boundary = visibility), where every block redundantly sums them, solves
- *     the 6x6 system by LDL^T in fp64, applies exp(delta) to the pose and evaluates the stopping
- *     tests while its own data-pixel loads are already in flight.  This removed a store-ack wait,
- *     a ticket atomic and an L1-bypassing reload from the critical path of every iteration
- *     (19 -> see profiles/).  State and partials are double buffered by launch parity; block 0
- *     writes the state.  The next iteration is just the next launch: no host round trip.
+ *   - per-lane int64 accumulators -> wave butterfly (stages 32 / 16 on v_permlane32/16_swap, the rest
+ *     ds_bpermute) -> LDS across the 8 waves -> the block's 32 sums are ADDED into one of ICP_RECORDS (8) rotating
+ *     accumulator records per hypothesis with memory-side 64-bit atomics (exact integers: order immaterial);
+ *   - no in-kernel hand-off: the records of launch j are consumed by the PROLOGUE of launch j+1 (kernel
+ *     boundary = visibility), where every block redundantly totals them (2 KB), solves the 6x6 system by LDL^T
+ *     in fp64, applies exp(delta) to the pose and evaluates the stopping tests while its own data-pixel loads
+ *     are already in flight.  Three record sets rotate (read / add / zero for the next launch); the state is
+ *     double buffered by launch parity; block 0 writes it.  The next iteration is just the next launch: no host
+ *     round trip.  The closing launch (k_icp_finish, one block) only consumes and reports into a pinned host
+ *     record; the objective-only statistics pass closes itself (last block totals and reports).
  */
 #include "suma_internal.h"
 
@@ -410,16 +411,17 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         gout->valid = (uint32_t)s_wave[0][29];
         gout->outlier = (uint32_t)s_wave[0][30];
         gout->invalid = (uint32_t)s_wave[0][31];
-        if (g.eval_only) { /* Objective::jacobianProducts outputs */
+        if (g.eval_only) /* Objective::jacobianProducts: the raw fixed-point words */
           for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = s_wave[0][w];
-          int k = 0;
-          for (int i = 0; i < 6; ++i)
-            for (int j = i; j < 6; ++j) {
-              const double v = s_val[k++];
-              gout->JtJ[6 * j + i] = v;
-              gout->JtJ[6 * i + j] = v;
-            }
-          for (int i = 0; i < 6; ++i) gout->Jtr[i] = s_val[21 + i];
+      }
+      if (blockIdx.x == 0 && lane < 42) {
+        /* JtJ / Jtf of this step, one element per lane: jacobianProducts' outputs and LieGaussNewton::information_
+         * (LieGaussNewton.cpp:75); the symmetric matrix is mirrored from the packed upper triangle */
+        if (lane < 36) {
+          const int i = lane % 6, j = lane / 6, lo = i < j ? i : j, hi = i < j ? j : i;
+          gout->JtJ[lane] = s_val[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+        } else {
+          gout->Jtr[lane - 36] = s_val[21 + (lane - 36)];
         }
       }
       uint32_t k = gin->k, n_hist = gin->n_hist, converged = gin->converged, hist_slot = 0xffffffffu;
@@ -514,8 +516,11 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     gout->valid = gin->valid;
     gout->outlier = gin->outlier;
     gout->invalid = gin->invalid;
-    if (done_in)
+    if (done_in) {
       for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = gin->acc[w];
+      for (int w = 0; w < 36; ++w) gout->JtJ[w] = gin->JtJ[w]; /* information() of a chain that has converged */
+      for (int w = 0; w < 6; ++w) gout->Jtr[w] = gin->Jtr[w];
+    }
   }
 
   if (!PIXEL || (done && !g.eval_only) || (g.eval_only && pending)) {
@@ -739,15 +744,16 @@ static IcpArgs make_args(suma_ctx* c) {
   a.Hm = (int32_t)mod->height;
   a.fov_up = c->pd.fov_up;
   a.fov = c->pd.fov;
-  /* Frame2Model.cpp:66-67 */
-  a.angle_thresh = (float)cos((double)c->p.icp_max_angle * M_PI / 180.0);
-  a.distance_thresh = c->p.icp_max_distance;
-  a.factor = c->p.factor;
+  /* Frame2Model.cpp:66-67; an adapter-side Frame2Model object may carry its own values (suma_icp_set_objective) */
+  const float max_angle = c->obj_set ? c->obj.icp_max_angle : c->p.icp_max_angle;
+  a.angle_thresh = (float)cos((double)max_angle * M_PI / 180.0);
+  a.distance_thresh = c->obj_set ? c->obj.icp_max_distance : c->p.icp_max_distance;
+  a.factor = c->obj_set ? c->obj.factor : c->p.factor;
   a.k8_enabled = 0;
   a.k8 = launch_k8_out(c);
   a.k8_ds = c->ds;
-  a.weight_function = c->p.weight_function;
-  a.bilinear = c->p.bilinear_sampling;
+  a.weight_function = c->obj_set ? c->obj.weight_function : c->p.weight_function;
+  a.bilinear = c->obj_set ? c->obj.bilinear_sampling : c->p.bilinear_sampling;
   a.P = (uint32_t)a.W * (uint32_t)a.H;
   return a;
 }

@@ -245,6 +245,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   c->scan_points = nullptr;
   c->scan_labels = c->scan_probs = nullptr;
   c->icp_current = c->icp_model = nullptr;
+  c->obj_set = false;
   derive(c);
   c->P = (size_t)params->data_width * params->data_height;
   c->Pm = (size_t)params->model_width * params->model_height;
@@ -414,6 +415,24 @@ extern "C" void* suma_frame_device_ptr(const suma_frame* f, int which) {
   return (f && which >= 0 && which <= 2) ? (void*)f->map[which] : nullptr;
 }
 
+extern "C" int suma_frame_swap(suma_ctx* c, suma_frame* a, suma_frame* b) {
+  if (!c || !a || !b) return SUMA_ERR_INVALID;
+  if (a->width != b->width || a->height != b->height) return fail(c, SUMA_ERR_INVALID, "suma_frame_swap: sizes differ");
+  for (int m = 0; m < 3; ++m) std::swap(a->map[m], b->map[m]);
+  c->rendered.valid = false;
+  if (c->k8_fused_frame == a || c->k8_fused_frame == b) c->k8_fused_frame = nullptr;
+  return SUMA_OK;
+}
+extern "C" int suma_frame_export(suma_ctx* c, const suma_frame* f, int which, void** d_ptr, uint32_t* width,
+                                 uint32_t* height, uint32_t* row_bytes) {
+  if (!c || !f || !d_ptr || which < 0 || which > 2) return SUMA_ERR_INVALID;
+  *d_ptr = (void*)f->map[which];
+  if (width) *width = f->width;
+  if (height) *height = f->height;
+  if (row_bytes) *row_bytes = f->width * (uint32_t)sizeof(float4);
+  return SUMA_OK;
+}
+
 extern "C" int suma_device_alloc(suma_ctx* c, uint64_t bytes, void** d_ptr) {
   if (!c || !d_ptr) return SUMA_ERR_INVALID;
   CK(hipMalloc(d_ptr, bytes ? bytes : 16));
@@ -427,6 +446,13 @@ extern "C" int suma_device_free(suma_ctx* c, void* d_ptr) {
 extern "C" int suma_device_upload(suma_ctx* c, void* d_dst, const void* host_src, uint64_t bytes) {
   if (!c || !d_dst || !host_src) return SUMA_ERR_INVALID;
   CK(hipMemcpyAsync(d_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  return SUMA_OK;
+}
+
+extern "C" int suma_device_download(suma_ctx* c, void* host_dst, const void* d_src, uint64_t bytes) {
+  if (!c || !host_dst || !d_src) return SUMA_ERR_INVALID;
+  CK(hipMemcpyAsync(host_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   return SUMA_OK;
 }
@@ -480,6 +506,20 @@ extern "C" int suma_icp_set_data(suma_ctx* c, const suma_frame* current, const s
   if (!c || !current || !model) return SUMA_ERR_INVALID;
   c->icp_current = current;
   c->icp_model = model;
+  return SUMA_OK;
+}
+
+extern "C" int suma_icp_set_objective(suma_ctx* c, const suma_icp_objective* o) {
+  if (!c) return SUMA_ERR_INVALID;
+  c->obj_set = (o != nullptr);
+  if (o) c->obj = *o;
+  return SUMA_OK;
+}
+/* LieGaussNewton::information(): JtJ of the last step, as left in the pinned state copy by the last
+ * suma_icp_minimize / suma_icp_jacobian_products */
+extern "C" int suma_icp_information(suma_ctx* c, double information[36]) {
+  if (!c || !information) return SUMA_ERR_INVALID;
+  memcpy(information, c->h_gn[0].JtJ, 36 * sizeof(double));
   return SUMA_OK;
 }
 
@@ -547,25 +587,45 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
   return SUMA_OK;
 }
 
-/* enqueue one whole minimisation (no host round trip inside) */
+/* enqueue one whole minimisation.  max iterations > 0: no host round trip inside.  max iterations == 0 means
+ * "iterate until convergence" in the reference (LieGaussNewton.cpp:27): launches are enqueued in chunks and the
+ * chains' done flags polled in between, so 0 really runs until every chain has converged; a chain that has not
+ * converged after SUMA_GN_HARD_CAP iterations is reported as an error instead of returned silently. */
+#define SUMA_GN_CHUNK 32u
+#define SUMA_GN_HARD_CAP (1u << 16)
 static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history) {
-  uint32_t max_iter = c->p.max_iterations;
-  uint32_t launches = max_iter > 0 ? max_iter : 1000; /* reference: 0 = until convergence (LieGaussNewton.cpp:27) */
+  const uint32_t max_iter = c->p.max_iterations;
+  const uint32_t iter_arg = max_iter > 0 ? max_iter : 0xffffffffu;
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
-  const double chain_bytes = 96.0 * (double)c->icp_current->width * c->icp_current->height * n_hyp * launches;
-  {
+  const double launch_bytes = 96.0 * (double)c->icp_current->width * c->icp_current->height * n_hyp;
+  if (max_iter > 0) {
     /* one event pair around the whole chain of identical pixel launches: per-launch time = chain / N */
-    ProfScope ps(c, "k6_icp_step", chain_bytes, launches);
-    for (uint32_t i = 0; i < launches; ++i)
-      CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
-                              (double)c->p.delta, 0, with_history, 1));
+    ProfScope ps(c, "k6_icp_step", launch_bytes * max_iter, max_iter);
+    for (uint32_t i = 0; i < max_iter; ++i)
+      CK(launch_icp_iteration(c, n_hyp, iter_arg, (double)c->p.stopping_threshold, (double)c->p.delta, 0, with_history, 1));
+  } else {
+    uint32_t total = 0;
+    for (;;) {
+      {
+        ProfScope ps(c, "k6_icp_step", launch_bytes * SUMA_GN_CHUNK, SUMA_GN_CHUNK);
+        for (uint32_t i = 0; i < SUMA_GN_CHUNK; ++i)
+          CK(launch_icp_iteration(c, n_hyp, iter_arg, (double)c->p.stopping_threshold, (double)c->p.delta, 0, with_history, 1));
+      }
+      total += SUMA_GN_CHUNK;
+      CK(hipMemcpyAsync(c->h_gn, gn_result(c), (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+      CK(hipStreamSynchronize(c->stream));
+      bool all_done = true;
+      for (uint32_t h = 0; h < n_hyp; ++h) all_done = all_done && c->h_gn[h].done;
+      if (all_done) break;
+      if (total >= SUMA_GN_HARD_CAP)
+        return fail(c, SUMA_ERR_INVALID, "Gauss-Newton did not converge within 65536 iterations (max iterations = 0)");
+    }
   }
   {
     ProfScope ps(c, "k6_icp_finish", 0.0);
-    CK(launch_icp_iteration(c, n_hyp, max_iter > 0 ? max_iter : 0xffffffffu, (double)c->p.stopping_threshold,
-                            (double)c->p.delta, 0, with_history, 0));
+    CK(launch_icp_iteration(c, n_hyp, iter_arg, (double)c->p.stopping_threshold, (double)c->p.delta, 0, with_history, 0));
   }
   return SUMA_OK;
 }
@@ -818,6 +878,23 @@ extern "C" int suma_map_download(suma_ctx* c, suma_surfel* host, uint32_t cap, u
   }
   return SUMA_OK;
 }
+extern "C" int suma_map_export_surfels(suma_ctx* c, void** d_ptr, uint32_t* n) {
+  if (!c || !d_ptr || !n) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  *d_ptr = (void*)c->surfels[c->cur];
+  *n = c->h_ds->n_surfels;
+  return check_overflow(c);
+}
+extern "C" int suma_map_export_data_surfels(suma_ctx* c, void** d_ptr, uint32_t* first, uint32_t* n_data) {
+  if (!c || !d_ptr || !first || !n_data) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  *d_ptr = (void*)c->surfels[c->cur];
+  *first = c->h_ds->n_kept_updated;
+  *n_data = c->h_ds->n_kept_data;
+  return check_overflow(c);
+}
 extern "C" int suma_map_upload(suma_ctx* c, const suma_surfel* host, uint32_t n, uint32_t timestamp) {
   if (!c || (!host && n)) return SUMA_ERR_INVALID;
   if (n > c->p.max_surfels) n = c->p.max_surfels;
@@ -930,7 +1007,7 @@ extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, 
 /* ---------------------------------------------------------------------------------------------
  * SurfelMapping::processScan
  * ------------------------------------------------------------------------------------------- */
-static void resolve_stats(suma_pipeline* s, bool need_sync);
+static int resolve_stats(suma_pipeline* s, bool need_sync);
 
 static void eye_d(double* T) {
   for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
@@ -997,6 +1074,7 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
 }
 extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
   if (!s) return;
+  ingest_destroy(s);
   if (s->c && s->c->stream) hipStreamSynchronize(s->c->stream);
   suma_frame_destroy(s->last_frame);
   suma_frame_destroy(s->current_frame);
@@ -1019,9 +1097,9 @@ extern "C" int suma_pipeline_last_increment(const suma_pipeline* s, double inc[1
 }
 extern "C" int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st) {
   if (!s || !st) return SUMA_ERR_INVALID;
-  resolve_stats(const_cast<suma_pipeline*>(s), true);
+  int r = resolve_stats(const_cast<suma_pipeline*>(s), true);
   *st = s->stats;
-  return SUMA_OK;
+  return r;
 }
 extern "C" uint32_t suma_pipeline_timestamp(const suma_pipeline* s) { return s ? s->timestamp : 0; }
 extern "C" uint32_t suma_pipeline_track_loss(const suma_pipeline* s) { return s ? s->track_loss : 0; }
@@ -1030,22 +1108,23 @@ extern "C" suma_frame* suma_pipeline_frame(suma_pipeline* s, int which) {
   return which == 0 ? s->current_frame : (which == 1 ? s->last_model : s->current_model);
 }
 
-/* the stream has been synchronised (or will be here): turn the pending statistics copy into s->stats */
-static void resolve_stats(suma_pipeline* s, bool need_sync) {
-  if (!s->stats_pending) return;
-  if (need_sync) hipStreamSynchronize(s->c->stream);
-  suma_icp_stats st;
-  const HostResult& hr = s->h_res[1 + s->stats_slot];
+/* the stream has been synchronised (or will be here): turn the pending statistics record into s->stats.  A
+ * record that was never stamped (the statistics launch faulted or was lost) is an error, not stale numbers. */
+static int resolve_stats(suma_pipeline* s, bool need_sync) {
+  if (!s->stats_pending) return SUMA_OK;
+  suma_ctx* c = s->c;
+  if (need_sync) CK(hipStreamSynchronize(c->stream));
   /* written by a launch that precedes, in stream order, either the synchronisation above or the
    * minimisation result the caller has just received */
-  while (__atomic_load_n(&hr.seq, __ATOMIC_ACQUIRE) != s->stats_seq) {
-    if (hipStreamQuery(s->c->stream) != hipErrorNotReady && __atomic_load_n(&hr.seq, __ATOMIC_ACQUIRE) != s->stats_seq) break;
-  }
-  fill_stats_host(hr, &st);
+  int r = wait_host_result(c, &s->h_res[1 + s->stats_slot], s->stats_seq);
+  s->stats_pending = false;
+  if (r) return fail(c, SUMA_ERR_HIP, "statistics pass did not report (launch failed?)");
+  suma_icp_stats st;
+  fill_stats_host(s->h_res[1 + s->stats_slot], &st);
   st.iterations = s->stats_mst.iterations;
   st.converged = s->stats_mst.converged;
   s->stats = st;
-  s->stats_pending = false;
+  return SUMA_OK;
 }
 
 /* SurfelMapping::getConfidenceThreshold, SurfelMapping.cpp:333-340 (time_init = 10) */
@@ -1081,7 +1160,8 @@ static int minimize_cfg(suma_pipeline* s, const suma_frame* cur, const suma_fram
     if (q == hipSuccess) break;
     if (q != hipErrorNotReady) CK(q);
   }
-  resolve_stats(s, false); /* everything enqueued before this point has completed */
+  int rs = resolve_stats(s, false); /* everything enqueued before this point has completed */
+  if (rs) return rs;
   c->known_surfels = c->h_ds->n_surfels;
   memcpy(T, c->h_gn[0].Tk, 16 * sizeof(double));
   fill_stats(c->h_gn[0], st);
@@ -1153,7 +1233,8 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   /* --- wait for the minimisation result only (poll on the record's sequence number) --- */
   int r = wait_host_result(c, &s->h_res[0], s->res_seq);
   if (r) return r;
-  resolve_stats(s, false); /* the previous scan's statistics launch precedes this result in the stream */
+  r = resolve_stats(s, false); /* the previous scan's statistics launch precedes this result in the stream */
+  if (r) return r;
   s->stats_slot = slot;
   *c->h_ds = s->h_res[0].ds;
   c->known_surfels = c->h_ds->n_surfels;

@@ -1,0 +1,116 @@
+/*
+ * suma_dist.hip -- libsuma_hip_dist.so: the one collective of the multi-GPU path, callable from a C++ host.
+ *
+ * The path shards over independent units only: one hypothesis or one sequence per GPU, one process
+ * per GPU, and per scan ONE all-gather of the ranks' results (16 doubles of pose + a few statistics, ~150 bytes) so
+ * that every rank can pick the same winner -- the pattern of the reference's loop-closure verification, which
+ * tries several initialisations in sequence on one GPU (SurfelMapping.cpp:662-779).  The collective is latency
+ * bound; it runs on the ctx stream behind the minimisation whose result it carries.
+ *
+ * Kept in its own library so that libsuma_hip.so does not depend on RCCL: single-GPU integrations never load it.
+ * Python hosts use torch.distributed (backend "nccl" = RCCL) for the same gather (semantic_suma_amd/distributed.py).
+ */
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <string.h>
+
+#include <new>
+#include <string>
+
+#include "../../include/suma_hip_dist.h"
+
+#define SUMA_DIST_MAX_DOUBLES 64u
+
+struct suma_dist_comm {
+  ncclComm_t comm;
+  int world, rank;
+  double *d_send, *d_recv; /* device staging */
+  double* h_buf;           /* pinned: send block followed by world receive blocks */
+  std::string err;
+};
+
+static thread_local std::string g_dist_error;
+
+extern "C" const char* suma_dist_last_error(const suma_dist_comm* c) { return c ? c->err.c_str() : g_dist_error.c_str(); }
+
+extern "C" int suma_dist_unique_id(char id[SUMA_DIST_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= SUMA_DIST_ID_BYTES, "ncclUniqueId does not fit");
+  ncclUniqueId u;
+  ncclResult_t r = ncclGetUniqueId(&u);
+  if (r != ncclSuccess) {
+    g_dist_error = std::string("ncclGetUniqueId: ") + ncclGetErrorString(r);
+    return SUMA_ERR_HIP;
+  }
+  memset(id, 0, SUMA_DIST_ID_BYTES);
+  memcpy(id, &u, sizeof(u));
+  return SUMA_OK;
+}
+
+extern "C" int suma_dist_comm_create(const char id[SUMA_DIST_ID_BYTES], int world, int rank, suma_dist_comm** out) {
+  if (!id || !out || world < 1 || rank < 0 || rank >= world) return SUMA_ERR_INVALID;
+  *out = nullptr;
+  suma_dist_comm* c = new (std::nothrow) suma_dist_comm();
+  if (!c) return SUMA_ERR_NOMEM;
+  c->comm = nullptr;
+  c->world = world;
+  c->rank = rank;
+  c->d_send = c->d_recv = c->h_buf = nullptr;
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof(u));
+  ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank); /* on the calling thread's current HIP device */
+  if (r != ncclSuccess) {
+    g_dist_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);
+    delete c;
+    return SUMA_ERR_HIP;
+  }
+  const size_t blk = SUMA_DIST_MAX_DOUBLES * sizeof(double);
+  if (hipMalloc((void**)&c->d_send, blk) != hipSuccess || hipMalloc((void**)&c->d_recv, blk * (size_t)world) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_buf, blk * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) {
+    g_dist_error = "suma_dist_comm_create: staging allocation failed";
+    suma_dist_comm_destroy(c);
+    return SUMA_ERR_HIP;
+  }
+  *out = c;
+  return SUMA_OK;
+}
+
+extern "C" void suma_dist_comm_destroy(suma_dist_comm* c) {
+  if (!c) return;
+  if (c->d_send) hipFree(c->d_send);
+  if (c->d_recv) hipFree(c->d_recv);
+  if (c->h_buf) hipHostFree(c->h_buf);
+  if (c->comm) ncclCommDestroy(c->comm);
+  delete c;
+}
+
+extern "C" int suma_gather(suma_ctx* ctx, suma_dist_comm* c, const double* send, uint32_t count, double* all) {
+  if (!ctx || !c || !send || !all || count == 0 || count > SUMA_DIST_MAX_DOUBLES) return SUMA_ERR_INVALID;
+  hipStream_t stream = (hipStream_t)suma_ctx_stream(ctx);
+  const size_t bytes = (size_t)count * sizeof(double);
+  memcpy(c->h_buf, send, bytes);
+#define DTRY(expr)                                                      \
+  do {                                                                  \
+    hipError_t e__ = (expr);                                            \
+    if (e__ != hipSuccess) {                                            \
+      c->err = std::string(#expr) + ": " + hipGetErrorString(e__);      \
+      return SUMA_ERR_HIP;                                              \
+    }                                                                   \
+  } while (0)
+  DTRY(hipMemcpyAsync(c->d_send, c->h_buf, bytes, hipMemcpyHostToDevice, stream));
+  ncclResult_t r = ncclAllGather(c->d_send, c->d_recv, count, ncclDouble, c->comm, stream);
+  if (r != ncclSuccess) {
+    c->err = std::string("ncclAllGather: ") + ncclGetErrorString(r);
+    return SUMA_ERR_HIP;
+  }
+  double* h_recv = c->h_buf + SUMA_DIST_MAX_DOUBLES;
+  DTRY(hipMemcpyAsync(h_recv, c->d_recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost, stream));
+  DTRY(hipStreamSynchronize(stream));
+#undef DTRY
+  memcpy(all, h_recv, bytes * (size_t)c->world);
+  return SUMA_OK;
+}
+
+extern "C" int suma_gather_poses(suma_ctx* ctx, suma_dist_comm* c, const double pose[16], double* all_poses) {
+  return suma_gather(ctx, c, pose, 16, all_poses);
+}

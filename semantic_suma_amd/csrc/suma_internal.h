@@ -109,6 +109,8 @@ struct suma_ctx {
 
   /* ICP */
   const suma_frame *icp_current, *icp_model;
+  suma_icp_objective obj; /* per-object Frame2Model parameters of the adapter (suma_icp_set_objective) */
+  bool obj_set;
   GnState* gn;        /* 2 x SUMA_MAX_HYP states, alternating with the launch parity */
   int64_t* gn_partial; /* 3 rotating sets of SUMA_MAX_HYP x ICP_RECORDS x SUMA_ACC_WORDS accumulators (k_icp.hip) */
   uint32_t gn_part_launch;   /* rotation counter, never reset */
@@ -205,7 +207,11 @@ struct suma_pipeline {
   bool stats_pending;
   uint32_t stats_slot;
   suma_icp_stats stats_mst;
+  struct Ingest* ingest; /* pinned double-buffered scan staging + copy stream + ingest thread (suma_ingest.hip) */
 };
+
+/* suma_ingest.hip */
+void ingest_destroy(suma_pipeline* s);
 
 #define HIP_TRY(ctx, expr)                                                                       \
   do {                                                                                           \

@@ -177,7 +177,7 @@ def test_gauss_newton_convergence_and_batch(hip, oracle_lib):
             a = np.deg2rad(rng.uniform(-2, 2))
             T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
         T0s.append(T)
-    Ts, stats = gn.minimize_batch(T0s)
+    Ts, stats = gn.minimize_batch(T0s, obj)
     for k in range(8):
         To, _, st = ora.minimize(f1, f0, T0s[k])
         assert np.array_equal(Ts[k], To), f"hypothesis {k}"
@@ -569,3 +569,178 @@ def test_loop_closure_verification(hip, oracle_lib):
             assert (c["valid"], c["outlier"], c["invalid"], c["error"]) == (sc.valid, sc.outlier, sc.invalid, sc.error)
             assert np.array_equal(res[k]["JtJ"], JtJ)
     assert n_passed >= 1, "test setup: at least one guess should pass the gates"
+
+
+def test_two_objectives_with_their_own_gates(hip, oracle_lib):
+    """objective_ and recovery_ = Frame2Model(fallback_params) (SurfelMapping.cpp:87-94) live side by side on one
+    context: each object sends its own gates and its own frame pair before a launch (round-1 advisor finding)."""
+    p = params_with_size(900)
+    p_fb = params_with_size(900, icp_max_distance=p.fallback_max_distance, icp_max_angle=p.fallback_max_angle)
+    ora, f0, f1 = _model_and_data(oracle_lib, p, 900, True)
+    ora_fb = oracle_lib.Oracle(p_fb)
+    pts2, l2, pr2, _ = get_scan(3, 900, True)
+    f2 = ora.preprocess(pts2, l2, pr2, 22, ora.frame())
+    ctx = hip.Context(p)
+    h0, h1, h2 = (hip.Frame(ctx, 900, 64) for _ in range(3))
+    for h, f in ((h0, f0), (h1, f1), (h2, f2)):
+        h.set(f.vertex, f.normal, f.semantic)
+    objective, recovery = hip.Frame2Model(ctx), hip.Frame2Model(ctx, p_fb)
+    objective.setData(h1, h0)
+    recovery.setData(h2, h1)  # another pair: the last setData on the context must not leak into `objective`
+    gn = hip.LieGaussNewton(ctx)
+    T0 = np.eye(4)
+    T0[0, 3] = 1.0
+    for _ in range(2):  # interleaved
+        gn.minimize(objective, T0)
+        To, _, st = ora.minimize(f1, f0, T0)
+        assert np.array_equal(gn.pose(), To) and objective.valid() == st.valid and objective.outlier() == st.outlier
+        info = gn.information()
+        assert np.array_equal(info, info.T) and np.all(np.diag(info) > 0)
+        gn.minimize(recovery, T0 @ T0)
+        To, _, st = ora_fb.minimize(f2, f1, T0 @ T0)
+        assert np.array_equal(gn.pose(), To) and recovery.outlier() == st.outlier
+    # information() = JtJ of the last step: jacobianProducts at the pose before the last increment reproduces it
+    p1 = params_with_size(900, max_iterations=1)
+    ctx.set_params(p1)
+    gn.minimize(objective, T0)
+    info = gn.information()
+    objective.initialize(T0)
+    _, JtJ, _ = objective.jacobianProducts()
+    assert np.array_equal(info, JtJ)
+    # setParameter reaches only its own object
+    recovery.setParameter("icp-max-distance", 0.05)
+    recovery.initialize(T0 @ T0)
+    recovery.jacobianProducts()
+    p_tight = params_with_size(900, icp_max_distance=0.05, icp_max_angle=p.fallback_max_angle)
+    _, acc, _, _, _ = oracle_lib.Oracle(p_tight).jacobian_products(f2, f1, T0 @ T0, 0)
+    assert np.array_equal(recovery.acc, acc)
+    objective.initialize(T0)
+    objective.jacobianProducts()
+    assert np.array_equal(objective.acc, ora.jacobian_products(f1, f0, T0, 0)[1])
+    assert hip.LieGaussNewton.reason(-1).startswith("Maximum") and hip.LieGaussNewton.reason(0) == "no error"
+
+
+def test_minimize_until_convergence(hip, oracle_lib):
+    """max iterations = 0 means "until convergence" (LieGaussNewton.cpp:27): launches are enqueued in chunks of 32 and
+    the done flags polled -- no silent cap (round-1 advisor finding)"""
+    p0 = params_with_size(900)
+    ora, f0, f1 = _model_and_data(oracle_lib, p0, 900, False)
+    ctx = hip.Context(p0)
+    h0, h1 = hip.Frame(ctx, 900, 64), hip.Frame(ctx, 900, 64)
+    h0.set(f0.vertex, f0.normal, f0.semantic)
+    h1.set(f1.vertex, f1.normal, f1.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    gn = hip.LieGaussNewton(ctx)
+    T0 = np.eye(4)
+    T0[0, 3] = 1.0
+    longest = 0
+    for eps, delta in ((0.5, 2e-3), (0.05, 1e-3)):  # the oracle converges after 27 / 136 iterations
+        # (the oracle has no cap either: ask it with a finite budget first)
+        ora.set_params(params_with_size(900, max_iterations=400, stopping_threshold=eps, delta=delta))
+        To, _, st = ora.minimize(f1, f0, T0)
+        assert st.converged == 1, "test setup"
+        ctx.set_params(params_with_size(900, max_iterations=0, stopping_threshold=eps, delta=delta))
+        gn.minimize(obj, T0, history_cap=0)
+        assert np.array_equal(gn.pose(), To), f"thresholds {eps} / {delta}"
+        assert gn.stats.converged == 1 and gn.iterationCount() == st.iterations
+        longest = max(longest, st.iterations)
+    assert longest > 64, "no chain crossed a chunk boundary"
+
+
+def test_frame_swap_and_viewer_exports(hip, oracle_lib):
+    """suma_frame_swap, suma_frame_export, suma_map_export_surfels / _data_surfels: the buffers a viewer would
+    register with hipGraphicsGLRegisterBuffer / Image hold exactly what the download entry points return."""
+    width = 900
+    p = params_with_size(width)
+    hp = hip.SurfelMapping(p)
+    for k in range(3):
+        pts, lab, prob, _ = get_scan(k, width, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=5)
+    ctx = hp.ctx
+    surfels = hp.map.getAllSurfels()
+    d_ptr, n = hp.map.getModelSurfels()
+    assert n == surfels.shape[0] and d_ptr
+    assert ctx.device_download(d_ptr, 64 * n).tobytes() == surfels.tobytes()
+    d_ptr2, first, n_data = hp.map.getDataSurfels()
+    su, sn, _, _ = hp.map.counts()
+    assert d_ptr2 == d_ptr and first + n_data == n and 0 < n_data <= sn
+    tail = surfels[first:]
+    assert np.all(tail["timestamp"] == 2) and np.all(tail["count"] == 2.0)  # created by the last scan
+    f = hp.frame(2)
+    for which in range(3):
+        ptr, w, h, rb = f.export(which)
+        assert (w, h, rb) == (width, 64, 16 * width)
+        assert ctx.device_download(ptr, rb * h).tobytes() == f.download(which).tobytes()
+    a, b = hip.Frame(ctx, width, 64), hip.Frame(ctx, width, 64)
+    va = np.random.default_rng(0).random((64, width, 4), dtype=np.float32)
+    a.upload(0, va)
+    b.upload(0, 2 * va)
+    a.swap(b)
+    assert np.array_equal(a.download(0), 2 * va) and np.array_equal(b.download(0), va)
+    with pytest.raises(hip.SumaError):
+        a.swap(hip.Frame(ctx, 100, 10))
+
+
+def test_async_ingest_equals_resident_scans(hip):
+    """suma_pipeline_prefetch_scan / process_prefetched (pinned double buffer + copy stream + ingest thread): same
+    poses and map as the blocking host path, with scan k+1 staged while scan k runs (KITTIReader.cpp:136-203)."""
+    width, n = 900, 9
+    p = params_with_size(width)
+    scans_ = [get_scan(k, width, True)[:3] for k in range(n)]
+    ref = hip.SurfelMapping(p)
+    for pts, lab, prob in scans_:
+        ref.processScan(pts, lab, prob, fixed_iterations=10)
+    a = hip.SurfelMapping(p)
+    seen = []
+    assert a.processSequence(scans_, fixed_iterations=10, on_scan=lambda k, s: seen.append(s.getCurrentPose().copy())) == n
+    assert np.array_equal(a.getCurrentPose(), ref.getCurrentPose()) and len(seen) == n
+    assert a.map.getAllSurfels().tobytes() == ref.map.getAllSurfels().tobytes()
+    # one-call form, scans of different sizes (staging grows), no labels, an empty scan
+    b, c = hip.SurfelMapping(p), hip.SurfelMapping(p)
+    odd = [(scans_[0][0][:5000], None, None), (scans_[1][0], None, None), (np.zeros((0, 4), np.float32), None, None),
+           (scans_[2][0], None, None)]
+    for pts, lab, prob in odd:
+        b.ctx.check(b.L.suma_pipeline_process_scan_async(b.h, pts.ctypes.data if pts.size else None, None, None,
+                                                         pts.shape[0], 5), "async")
+        c.processScan(pts, lab, prob, fixed_iterations=5)
+    assert b.getCurrentPose().tobytes() == c.getCurrentPose().tobytes()  # NaN after the empty scan, on both paths
+    assert b.map.getAllSurfels().tobytes() == c.map.getAllSurfels().tobytes()
+    # misuse is reported
+    with pytest.raises(hip.SumaError):
+        a.processPrefetched()
+    a.prefetchScan(*scans_[0])
+    a.prefetchScan(*scans_[1])
+    with pytest.raises(hip.SumaError):
+        a.prefetchScan(*scans_[2])  # both slots staged
+
+
+def test_gather_poses_rccl_world_1(hip):
+    """libsuma_hip_dist.so: the C-ABI gather (RCCL all-gather on the ctx stream).  A 1-GPU box can only host a
+    communicator of size 1 (RCCL refuses two ranks on one device); the N-rank path is exercised by bench.py --gpus N."""
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(hip.LIB_PATH), "libsuma_hip_dist.so")
+    D = C.CDLL(path)
+    vp = C.c_void_p
+    D.suma_dist_unique_id.argtypes = [vp]
+    D.suma_dist_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    D.suma_dist_comm_destroy.argtypes = [vp]
+    D.suma_gather_poses.argtypes = [vp, vp, vp, vp]
+    D.suma_gather.argtypes = [vp, vp, vp, C.c_uint32, vp]
+    D.suma_dist_last_error.restype = C.c_char_p
+    D.suma_dist_last_error.argtypes = [vp]
+    ctx = hip.Context(params_with_size(900))
+    uid = C.create_string_buffer(128)
+    assert D.suma_dist_unique_id(uid) == 0, D.suma_dist_last_error(None)
+    comm = vp()
+    assert D.suma_dist_comm_create(uid, 1, 0, C.byref(comm)) == 0, D.suma_dist_last_error(None)
+    pose = np.arange(16, dtype=np.float64) + 0.5
+    out = np.zeros(16, dtype=np.float64)
+    assert D.suma_gather_poses(ctx.h, comm, pose.ctypes.data, out.ctypes.data) == 0, D.suma_dist_last_error(comm)
+    assert np.array_equal(out, pose)
+    payload = np.linspace(0, 1, 21)
+    out2 = np.zeros(21)
+    assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 21, out2.ctypes.data) == 0 and np.array_equal(out2, payload)
+    assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 65, out2.ctypes.data) != 0  # over the 64-double limit
+    D.suma_dist_comm_destroy(comm)

@@ -20,10 +20,10 @@ gn = core.LieGaussNewton(ctx)
 T0 = np.eye(4); T0[0, 3] = 1.0
 for n in (1, 2, 4, 8, 16, 32):
     starts = hypothesis_starts(T0, n)
-    gn.minimize_batch(starts)
+    gn.minimize_batch(starts, obj)
     ctx.profile(1); ctx.profile_reset()
     t = time.perf_counter()
-    for _ in range(10): Ts, st = gn.minimize_batch(starts)
+    for _ in range(10): Ts, st = gn.minimize_batch(starts, obj)
     dt = (time.perf_counter() - t) / 10
     k = [q for q in ctx.profile_get() if q['name'] == 'k6_icp_step'][0]
     us = 1000 * k['total_ms'] / k['launches']
