@@ -11,6 +11,7 @@
 #ifndef SUMA_ADAPTER_HPP_
 #define SUMA_ADAPTER_HPP_
 
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -88,24 +89,90 @@ class Preprocessing {
   Context& ctx_;
 };
 
-/* src/core/Objective.h:14-82 as implemented by src/core/Frame2Model.h:28-73 */
+/* SE3::exp (src/core/lie_algebra.cpp:4-34) for Objective::increment on the host side of the adapter; column-major */
+inline void se3_exp(const double* x, double* T) {
+  for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  const double v[3] = {x[0], x[1], x[2]}, o[3] = {x[3], x[4], x[5]};
+  const double theta = std::sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+  if (theta > 1e-10) {
+    const double K[9] = {0, -o[2], o[1], o[2], 0, -o[0], -o[1], o[0], 0}; /* row-major skew matrix */
+    double K2[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) K2[3 * r + c] = K[3 * r] * K[c] + K[3 * r + 1] * K[3 + c] + K[3 * r + 2] * K[6 + c];
+    const double alpha = std::sin(theta) / theta, beta = (1 - std::cos(theta)) / (theta * theta);
+    const double delta = (theta - std::sin(theta)) / (theta * theta * theta);
+    for (int r = 0; r < 3; ++r) {
+      double t = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        const double I = (r == c) ? 1.0 : 0.0;
+        T[4 * c + r] = I + alpha * K[3 * r + c] + beta * K2[3 * r + c];
+        t += (I + beta * K[3 * r + c] + delta * K2[3 * r + c]) * v[c];
+      }
+      T[12 + r] = t;
+    }
+  } else {
+    T[12] = v[0];
+    T[13] = v[1];
+    T[14] = v[2];
+  }
+}
+
+/* src/core/Objective.h:14-82 as implemented by src/core/Frame2Model.h:28-73.
+ * Like the reference's object, an instance OWNS its parameters (Frame2Model::updateParameters,
+ * Frame2Model.cpp:65-110) and its frame pair and sends both to the device before every launch: objective_ and
+ * recovery_ = Frame2Model(fallback_params) (SurfelMapping.cpp:87-94, used at :438-449) can share one Context. */
 class Frame2Model {
  public:
-  explicit Frame2Model(Context& ctx) : ctx_(ctx) { std::memset(&stats_, 0, sizeof(stats_)); eye(pose_); }
+  explicit Frame2Model(Context& ctx) : Frame2Model(ctx, ctx.params()) {}
+  /* Frame2Model(const rv::ParameterList&): the parameter block this objective is built from */
+  Frame2Model(Context& ctx, const suma_params& p) : ctx_(ctx) {
+    std::memset(&stats_, 0, sizeof(stats_));
+    eye(pose_);
+    objective_.icp_max_distance = p.icp_max_distance;
+    objective_.icp_max_angle = p.icp_max_angle;
+    objective_.weight_function = p.weight_function;
+    objective_.factor = p.factor;
+    objective_.bilinear_sampling = p.bilinear_sampling;
+  }
   uint32_t num_parameters() const { return 6; }
+  /* Objective::setParameter(const rv::Parameter&) -> Frame2Model::setParameter (Frame2Model.cpp:112-115): the keys
+   * this objective reads; "weighting" takes huber / turkey / stability / anything else = none */
+  void setParameter(const std::string& name, double value) {
+    if (name == "icp-max-distance") objective_.icp_max_distance = (float)value;
+    else if (name == "icp-max-angle") objective_.icp_max_angle = (float)value;
+    else if (name == "factor") objective_.factor = (float)value;
+    else if (name == "bilinear_sampling") objective_.bilinear_sampling = value != 0.0;
+  }
+  void setParameter(const std::string& name, const std::string& value) {
+    if (name != "weighting") return;
+    objective_.weight_function = value == "huber" ? SUMA_WEIGHT_HUBER
+                               : value == "turkey" ? SUMA_WEIGHT_TUKEY
+                               : value == "stability" ? SUMA_WEIGHT_STABILITY : SUMA_WEIGHT_NONE;
+  }
   void setData(const std::shared_ptr<Frame>& current, const std::shared_ptr<Frame>& last) {
     current_ = current;
     last_ = last;
-    check(ctx_.get(), suma_icp_set_data(ctx_.get(), current->get(), last->get()), "Frame2Model::setData");
     iteration_ = 0;
   }
   void initialize(const double* pose16) { std::memcpy(pose_, pose16, sizeof(pose_)); iteration_ = 0; }
+  /* Objective::residual is "not implemented" in the reference too (Frame2Model.cpp:131-134) */
+  double residual(const double* /*delta6*/) { throw std::runtime_error("not implemented."); }
   /* returns F; JtJ 6x6 column-major, Jtf 6 (Eigen::MatrixXd::data() of the reference's arguments) */
   double jacobianProducts(double* JtJ, double* Jtf) {
+    bind();
     check(ctx_.get(), suma_icp_jacobian_products(ctx_.get(), pose_, iteration_, JtJ, Jtf, nullptr, &stats_),
           "Frame2Model::jacobianProducts");
-    iteration_ += 1;
     return stats_.error;
+  }
+  /* Objective::increment (Objective.h:45-48): pose_ = SE3::exp(delta) * pose_ */
+  void increment(const double* delta6) {
+    double E[16], P[16];
+    se3_exp(delta6, E);
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r)
+        P[4 * c + r] = E[r] * pose_[4 * c] + E[4 + r] * pose_[4 * c + 1] + E[8 + r] * pose_[4 * c + 2] + E[12 + r] * pose_[4 * c + 3];
+    std::memcpy(pose_, P, sizeof(P));
+    iteration_ += 1;
   }
   const double* pose() const { return pose_; }
   uint32_t inlier() const { return stats_.inlier; }
@@ -113,13 +180,22 @@ class Frame2Model {
   uint32_t valid() const { return stats_.valid; }
   uint32_t invalid() const { return stats_.invalid; }
   double inlier_residual() const { return stats_.inlier_residual; }
+  void setLevel(uint32_t) {}                 /* Frame2Model.cpp:125 */
   uint32_t getMaxLevel() const { return 0; } /* Frame2Model.cpp:127-129 */
+  void reset() {}
 
  private:
   friend class LieGaussNewton;
   static void eye(double* T) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+  /* this object's frames and parameters become the ones the next launch uses */
+  void bind() {
+    if (!current_ || !last_) throw std::runtime_error("Frame2Model::setData has not been called");
+    check(ctx_.get(), suma_icp_set_data(ctx_.get(), current_->get(), last_->get()), "Frame2Model::setData");
+    check(ctx_.get(), suma_icp_set_objective(ctx_.get(), &objective_), "Frame2Model parameters");
+  }
   Context& ctx_;
   std::shared_ptr<Frame> current_, last_;
+  suma_icp_objective objective_;
   double pose_[16];
   uint32_t iteration_{0};
   suma_icp_stats stats_;
@@ -128,24 +204,38 @@ class Frame2Model {
 /* src/core/LieGaussNewton.h:25-76: the whole loop runs on the device */
 class LieGaussNewton {
  public:
+  static const int32_t CONVERGED = 0;
   explicit LieGaussNewton(Context& ctx) : ctx_(ctx) { std::memset(&stats_, 0, sizeof(stats_)); }
   int32_t minimize(Frame2Model& F, const double* T0) {
     history_.assign(16 * 1025, 0.0);
     uint32_t nh = 0;
+    F.bind();
     check(ctx_.get(), suma_icp_minimize(ctx_.get(), T0, pose_, history_.data(), 1025, &nh, &stats_),
           "LieGaussNewton::minimize");
     history_.resize(16 * (size_t)(nh < 1025 ? nh : 1025));
     std::memcpy(F.pose_, pose_, sizeof(pose_));
     F.stats_ = stats_;
-    return 0;
+    F.iteration_ = stats_.iterations;
+    check(ctx_.get(), suma_icp_information(ctx_.get(), information_), "LieGaussNewton::information");
+    return 0; /* the reference returns 0 from every path of minimize (LieGaussNewton.cpp:37) */
   }
   const double* pose() const { return pose_; }
+  double residual() const { return stats_.error; }
+  /* LieGaussNewton::reason (LieGaussNewton.cpp:110-115), called by SurfelMapping.cpp:428,448 */
+  std::string reason(int32_t errorno) const {
+    if (errorno == -1) return "Maximum number of iterations reached.";
+    if (errorno == -2) return "Diverging.";
+    return "no error";
+  }
+  /* information(): J^T W J of the last step, 6x6 column-major (LieGaussNewton.cpp:75,103-105) */
+  const double* information() const { return information_; }
   const std::vector<double>& history() const { return history_; } /* 16 doubles per entry */
   uint32_t iterationCount() const { return stats_.iterations; }
 
  private:
   Context& ctx_;
   double pose_[16];
+  double information_[36];
   std::vector<double> history_;
   suma_icp_stats stats_;
 };
@@ -182,6 +272,25 @@ class SurfelMap {
     uint32_t n = 0;
     check(ctx_.get(), suma_map_size(ctx_.get(), &n), "SurfelMap::size");
     return n;
+  }
+  /* getModelSurfels() / getDataSurfels() (SurfelMap.h:64-67) return glow::GlBuffer handles in the reference; here the
+   * device buffer of the active map (64-byte records, valid until the next update), for hipGraphicsGLRegisterBuffer
+   * or a device-to-device copy into the viewer's VBO.  The data surfels are the tail [first, first + n). */
+  struct DeviceSurfels {
+    const suma_surfel* d_ptr;
+    uint32_t first, n;
+  };
+  DeviceSurfels getModelSurfels() {
+    void* p = nullptr;
+    uint32_t n = 0;
+    check(ctx_.get(), suma_map_export_surfels(ctx_.get(), &p, &n), "SurfelMap::getModelSurfels");
+    return DeviceSurfels{(const suma_surfel*)p, 0, n};
+  }
+  DeviceSurfels getDataSurfels() {
+    void* p = nullptr;
+    uint32_t first = 0, n = 0;
+    check(ctx_.get(), suma_map_export_data_surfels(ctx_.get(), &p, &first, &n), "SurfelMap::getDataSurfels");
+    return DeviceSurfels{(const suma_surfel*)p, first, n};
   }
   std::vector<suma_surfel> getAllSurfels() {
     std::vector<suma_surfel> out(size());

@@ -366,7 +366,6 @@ class Frame2Model:
         self._bind()
         c.check(c.L.suma_icp_jacobian_products(c.h, _ptr(pose), self._iteration, _ptr(JtJ), _ptr(Jtr), _ptr(self.acc),
                                                C.byref(self.stats)), "suma_icp_jacobian_products")
-        self._iteration += 1
         return self.stats.error, JtJ.T.copy(), Jtr
 
     def increment(self, delta):

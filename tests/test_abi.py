@@ -18,8 +18,8 @@ def built():
     return core
 
 
-def declared_functions():
-    src = open(os.path.join(ROOT, "include", "suma_hip.h")).read()
+def declared_functions(header="suma_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set(re.findall(r"\b(suma_[a-z0-9_]+)\s*\(", src))
     return sorted(n for n in names if n not in ("suma_params_default",))
@@ -34,19 +34,33 @@ def test_every_declared_symbol_is_exported(built):
     assert b"gfx950" in C.c_char_p(C.cast(L.suma_version, C.CFUNCTYPE(C.c_char_p))()).value
 
 
+def test_dist_library_exports_its_header(built):
+    """libsuma_hip_dist.so (the RCCL gather, kept out of libsuma_hip.so) exports what include/suma_hip_dist.h declares;
+    libsuma_hip.so itself must not depend on RCCL"""
+    path = os.path.join(os.path.dirname(built.LIB_PATH), "libsuma_hip_dist.so")
+    L = C.CDLL(path)
+    names = declared_functions("suma_hip_dist.h")
+    assert {"suma_gather_poses", "suma_gather", "suma_dist_comm_create", "suma_dist_unique_id"} <= set(names)
+    assert not [n for n in names if not hasattr(L, n)]
+    needed = subprocess.check_output(["readelf", "-d", built.LIB_PATH]).decode()
+    assert "rccl" not in needed
+
+
 def test_ctypes_layouts_match_c(built, tmp_path):
-    from semantic_suma_amd.core import KernelTime
+    from semantic_suma_amd.core import IcpObjective, KernelTime, LoopResult
     from semantic_suma_amd.types import SURFEL_DTYPE, IcpStats, SumaParams
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "suma_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "suma_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(suma_params),sizeof(suma_icp_stats),sizeof(suma_surfel),sizeof(suma_kernel_time),"
-                   "offsetof(suma_params,max_surfels),offsetof(suma_params,cache_surfels));return 0;}\n")
+                   "offsetof(suma_params,max_surfels),offsetof(suma_params,cache_surfels),sizeof(suma_icp_objective),"
+                   "sizeof(suma_loop_result));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
     assert sizes[0] == C.sizeof(SumaParams) and sizes[1] == C.sizeof(IcpStats)
     assert sizes[2] == SURFEL_DTYPE.itemsize == 64 and sizes[3] == C.sizeof(KernelTime)
     assert sizes[4] == SumaParams.max_surfels.offset and sizes[5] == SumaParams.cache_surfels.offset
+    assert sizes[6] == C.sizeof(IcpObjective) and sizes[7] == C.sizeof(LoopResult)
 
 
 def test_no_cpu_fallback(built):
