@@ -12,10 +12,10 @@
  *   K12 extractSurfels                SurfelMap.cpp:708-742 + extract_surfels.vert:46-64
  *
  * GL structure replaced: transform feedback (an order-preserving append performed by the
- * fixed-function pipeline) becomes a single-pass stable compaction: every 256-surfel tile
- * computes its survivors, publishes its count in an 8-byte status word and obtains its output
- * offset by a decoupled look-back over the preceding tiles' words (tile ids handed out by an
- * atomic ticket, so predecessors are always running; two-level variant, see lookback_prefix).
+ * fixed-function pipeline) becomes a single-pass stable compaction: every SUMA_TILE (1024) surfel tile
+ * computes its survivors, publishes its count in an 8-byte status word {30-bit launch epoch, flag, count} and in
+ * the accumulator of its group of 64 tiles, and obtains its output offset from the preceding groups / tiles
+ * (tile ids handed out by an atomic ticket, so predecessors are always running; see lookback_prefix).
  * Output order = input order, exactly as transform feedback guarantees.  K11's area filter is evaluated inside K9 / K10, so the map is
  * read once and written once per scan instead of being copied a second time:
  *   traffic per scan = 64 B * (S + S_new) + the gathered measurement texels.
@@ -82,7 +82,7 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
     uint32_t spins = 0;
     do {
       w = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } while (((uint32_t)(w >> 34) != epoch || ((w >> 32) & 3ull) == 0) && ++spins < SUMA_SPIN_LIMIT);
+    } while (((uint32_t)(w >> 34) != (epoch & 0x3fffffffu) || ((w >> 32) & 3ull) == 0) && ++spins < SUMA_SPIN_LIMIT);
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
   }

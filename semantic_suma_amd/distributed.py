@@ -70,3 +70,133 @@ def gather_poses(local: np.ndarray, device=None) -> np.ndarray:
     outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, t)
     return np.stack([o.cpu().numpy() for o in outs])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# GPU-side runners for BASELINE configs 3 and 4.  They are written against a small engine interface so that the very
+# same orchestration code runs over the HIP path (HipEngine below) and, in the world-2 gloo tests on CPU, over a
+# stand-in engine built by the test.
+# ---------------------------------------------------------------------------------------------------------------
+
+def conf_threshold(params, t: int) -> float:
+    """SurfelMapping::getConfidenceThreshold (SurfelMapping.cpp:333-340, time_init = 10)"""
+    f = np.float32
+    ct = f(params.confidence_threshold)
+    if t < 10:
+        pu = f(0.1)
+        log_unstable = f(np.log(float(pu / (f(1.0) - pu))))
+        alpha = f(t) / f(10)
+        ct = f((1.0 - float(alpha)) * float(log_unstable) + float(alpha * f(params.confidence_threshold)))
+    return float(ct)
+
+
+def mul4(A, B):
+    """4x4 product in a fixed operation order (numpy's matmul may reorder / fuse): every rank must reach the same bits"""
+    C = np.zeros((4, 4))
+    for r in range(4):
+        for c in range(4):
+            C[r, c] = ((A[r, 0] * B[0, c] + A[r, 1] * B[1, c]) + A[r, 2] * B[2, c]) + A[r, 3] * B[3, c]
+    return C
+
+
+class HipEngine:
+    """One GPU's share of the hypothesis runner on the HIP path: Preprocessing, SurfelMap, Frame2Model and the
+    batched device-resident Gauss-Newton (suma_icp_minimize_batch) of one context."""
+
+    def __init__(self, params, device: int = 0):
+        from . import core
+        self.core = core
+        self.params = params
+        self.ctx = core.Context(params, device)
+        self.pre = core.Preprocessing(self.ctx)
+        self.map = core.SurfelMap(self.ctx)
+        self.objective = core.Frame2Model(self.ctx)
+        self.gn = core.LieGaussNewton(self.ctx)
+        self.current = core.Frame(self.ctx, params.data_width, params.data_height)
+        self.model = core.Frame(self.ctx, params.model_width, params.model_height)
+
+    def preprocess(self, points, labels, probs, t):
+        self.pre.process(points, self.current, labels, probs, t)
+
+    def render(self, pose, ct):
+        self.map.render(pose, pose, self.model, ct)
+
+    def minimize(self, starts):
+        """-> (poses [n, 4, 4], [(error, valid, outlier)] per start) against the rendered model"""
+        self.objective.setData(self.current, self.map.newMapFrame())
+        poses, stats = self.gn.minimize_batch(starts, self.objective)
+        return poses, [(s["error"], s["valid"], s["outlier"]) for s in stats]
+
+    def update(self, pose):
+        self.map.update(pose, self.current)
+
+    def map_bytes(self) -> bytes:
+        return self.map.getAllSurfels().tobytes()
+
+
+def run_hypotheses(engine, scans, n_hyp: int, rank: int = 0, world: int = 1, gather=gather_poses, on_scan=None):
+    """BASELINE config 3: per scan, n_hyp Gauss-Newton chains from perturbed starts (hypothesis k on rank k % world),
+    ONE all-gather of the results (18 doubles per hypothesis), the same winner on every rank, and the map update with
+    the winner's pose on every rank (maps stay identical without any map traffic).
+    Preprocessing and model rendering are done redundantly per rank (no traffic).
+    Returns (poses per scan [n, 4, 4], winners per scan)."""
+    params = engine.params
+    pose, increment = np.eye(4), np.eye(4)
+    poses, winners = [], []
+    for t, (pts, lab, prob) in enumerate(scans):
+        engine.preprocess(pts, lab, prob, t)
+        ct = conf_threshold(params, t)
+        engine.render(pose, ct)
+        if t > 0:
+            starts = hypothesis_starts(increment, n_hyp)
+            mine = list(range(rank, n_hyp, world))
+            local = np.zeros((n_hyp, 18))
+            if mine:
+                Ts, stats = engine.minimize([starts[k] for k in mine])
+                for j, k in enumerate(mine):
+                    local[k, :16] = np.asarray(Ts[j]).ravel()
+                    local[k, 16], local[k, 17] = stats[j][0], stats[j][1]
+            allr = gather(local).sum(axis=0) if world > 1 else local  # every hypothesis is owned by exactly one rank
+            win = pick_winner([(allr[k, 16], allr[k, 17]) for k in range(n_hyp)])
+            increment = allr[win, :16].reshape(4, 4).copy()
+            pose = mul4(pose, increment)
+            winners.append(win)
+        else:
+            winners.append(-1)
+        engine.update(pose)
+        poses.append(pose.copy())
+        if on_scan is not None:
+            on_scan(t, pose)
+    return np.stack(poses), winners
+
+
+def run_sequences(my_sequences, make_pipeline, scans_of, fixed_iterations: int = 0, threads: bool = True):
+    """BASELINE config 4: the sequences assigned to this rank (lpt_assign), each through its own pipeline
+    (make_pipeline() -> object with processScan(points, labels, probs, fixed_iterations) and getCurrentPose()).
+    A rank that owns several sequences runs them as concurrent pipelines on separate host threads and HIP streams
+    of its GPU (one context each): the single-sequence pipeline is latency bound and leaves most CUs idle.
+    Returns {sequence id: (n_scans, final pose)}; no collective in here."""
+    import threading
+    out, errors = {}, []
+
+    def run(seq):
+        try:
+            pipe = make_pipeline()
+            n = 0
+            for pts, lab, prob in scans_of(seq):
+                pipe.processScan(pts, lab, prob, fixed_iterations=fixed_iterations)
+                n += 1
+            out[seq] = (n, pipe.getCurrentPose())
+        except Exception as e:  # noqa: BLE001 -- reported to the caller below
+            errors.append((seq, repr(e)))
+
+    if threads and len(my_sequences) > 1:
+        th = [threading.Thread(target=run, args=(s,)) for s in my_sequences]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    else:
+        for s in my_sequences:
+            run(s)
+    if errors:
+        raise RuntimeError(f"sequence runs failed: {errors}")
+    return out

@@ -29,17 +29,34 @@ def read_velodyne(path: str) -> np.ndarray:
     return pts
 
 
+# SemanticKITTI learning_map (raw id -> one of RangeNet++'s 20 training classes) and learning_map_inv (training
+# class -> the raw id it is reported as).  The reference only ever sees learning_map_inv values: KITTIReader.cpp:189-200
+# assigns labels[i] = label_map_[argmax_j], j < 20.
+LEARNING_MAP = {0: 0, 1: 0, 10: 1, 11: 2, 13: 5, 15: 3, 16: 5, 18: 4, 20: 5, 30: 6, 31: 7, 32: 8, 40: 9, 44: 10, 48: 11,
+                49: 12, 50: 13, 51: 14, 52: 0, 60: 9, 70: 15, 71: 16, 72: 17, 80: 18, 81: 19, 99: 0, 252: 1, 253: 7,
+                254: 6, 255: 8, 256: 5, 257: 5, 258: 4, 259: 5}
+LEARNING_MAP_INV = {0: 0, 1: 10, 2: 11, 3: 15, 4: 18, 5: 20, 6: 30, 7: 31, 8: 32, 9: 40, 10: 44, 11: 48, 12: 49, 13: 50,
+                    14: 51, 15: 70, 16: 71, 17: 72, 18: 80, 19: 81}
+
+
+def remap_labels(raw_ids: np.ndarray) -> np.ndarray:
+    """raw SemanticKITTI ids -> the ids RangeNet++ would report: learning_map followed by learning_map_inv
+    (e.g. moving-car 252 -> 10, bus 13 / on-rails 16 / moving-bus 257 -> other-vehicle 20, lane-marking 60 -> road 40,
+    outlier 1 / other-structure 52 / other-object 99 -> unlabeled 0).  Unknown ids map to 0."""
+    lut = np.zeros(260, dtype=np.float32)
+    for raw, train in LEARNING_MAP.items():
+        lut[raw] = LEARNING_MAP_INV[train]
+    ids = np.asarray(raw_ids, dtype=np.int64)
+    return lut[np.where((ids >= 0) & (ids < 260), ids, 0)]
+
+
 def read_labels(path: str, n_points: int, prob: float = 1.0):
-    """SemanticKITTI .label -> (labels_float[N], labels_prob[N]); ground-truth labels carry probability `prob`"""
+    """SemanticKITTI .label -> (labels_float[N], labels_prob[N]) as the reference's reader would deliver them from
+    RangeNet++ (KITTIReader.cpp:175-200); ground-truth labels carry probability `prob`"""
     raw = np.fromfile(path, dtype="<u4")
     if raw.size != n_points:
         raise ValueError(f"{path}: {raw.size} labels for {n_points} points")
-    cls = (raw & 0xFFFF).astype(np.float32)
-    # moving classes 252..259 of SemanticKITTI map onto their static ids, as RangeNet++'s learning map does
-    moving = {252: 10, 253: 31, 254: 30, 255: 32, 256: 16, 257: 13, 258: 18, 259: 20}
-    for k, v in moving.items():
-        cls[cls == k] = v
-    return cls, np.full(n_points, prob, dtype=np.float32)
+    return remap_labels(raw & 0xFFFF), np.full(n_points, prob, dtype=np.float32)
 
 
 def read_calib(path: str) -> dict:

@@ -1,0 +1,83 @@
+"""GPU tests of the multi-GPU runners on ONE device (run with -m gpu): two processes (gloo rendezvous, both on
+device 0) drive the HIP path through semantic_suma_amd.distributed.run_hypotheses and must reach, rank for rank, the
+winners / poses / map of a single process that runs all hypotheses itself; config 4's runner with three
+sequences as concurrent pipelines on one GPU.  The RCCL collective itself needs one GPU per rank: bench.py --gpus N."""
+import hashlib
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from semantic_suma_amd.types import params_with_size
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+W, N_HYP, N_SCANS = 900, 8, 5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from semantic_suma_amd import synth
+    from semantic_suma_amd.distributed import HipEngine, run_hypotheses
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        p = params_with_size(W, max_iterations=8)
+        scans = [synth.generate_scan(k, n_azimuth=W)[:3] for k in range(N_SCANS)]
+        eng = HipEngine(p, device=0)
+        poses, winners = run_hypotheses(eng, scans, N_HYP, rank, world)
+        q.put((rank, world, poses, winners, hashlib.sha256(eng.map_bytes()).hexdigest()))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_hypotheses_two_ranks_one_device_equal_single_process():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs.append(ctx.Process(target=_worker, args=(0, 1, _free_port(), q)))
+    for pr in procs:
+        pr.start()
+    out = [q.get(timeout=600) for _ in procs]
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    ref = [o for o in out if o[1] == 1][0]
+    for o in out:
+        assert np.array_equal(o[2], ref[2]), f"rank {o[0]} of {o[1]}: poses differ from the single-process run"
+        assert o[3] == ref[3] and o[4] == ref[4]
+    assert ref[3][0] == -1 and all(0 <= w < N_HYP for w in ref[3][1:])
+    assert 3.0 < ref[2][-1][0, 3] < 6.0  # ~1.1 m per scan
+
+
+def test_sequences_as_concurrent_pipelines():
+    from semantic_suma_amd import core, synth
+    from semantic_suma_amd.distributed import lpt_assign, run_sequences
+    p = params_with_size(W)
+    lengths = [6, 4, 3]
+    assign, loads = lpt_assign(lengths, 1)
+
+    def scans_of(seq):
+        for k in range(lengths[seq]):
+            yield synth.generate_scan(50 * seq + k, n_azimuth=W)[:3]
+
+    a = run_sequences(assign[0], lambda: core.SurfelMapping(p), scans_of, fixed_iterations=10, threads=True)
+    b = run_sequences(assign[0], lambda: core.SurfelMapping(p), scans_of, fixed_iterations=10, threads=False)
+    assert sorted(a) == [0, 1, 2]
+    for s in a:
+        assert a[s][0] == lengths[s] and np.array_equal(a[s][1], b[s][1]), f"sequence {s}"

@@ -13,7 +13,7 @@ def test_sequence_roundtrip(tmp_path):
     rng = np.random.default_rng(0)
     raw = rng.normal(size=(1000, 4)).astype("<f4")
     raw.tofile(root / "velodyne" / "000000.bin")
-    lab = rng.choice([0, 10, 40, 50, 252, 259], 1000).astype("<u4") | (rng.integers(0, 100, 1000).astype("<u4") << 16)
+    lab = rng.choice([0, 1, 10, 13, 16, 40, 50, 52, 60, 99, 252, 256, 257, 259], 1000).astype("<u4") | (rng.integers(0, 100, 1000).astype("<u4") << 16)
     lab.tofile(root / "labels" / "000000.label")
     (root / "calib.txt").write_text("P0: " + " ".join(["1", "0", "0", "0", "0", "1", "0", "0", "0", "0", "1", "0"]) +
                                     "\nTr: 0 -1 0 0.1 0 0 -1 0.2 1 0 0 0.3\n")
@@ -22,7 +22,12 @@ def test_sequence_roundtrip(tmp_path):
     pts, labels, probs = seq[0]
     assert pts.dtype == np.float32 and pts.shape == (1000, 4)
     assert np.array_equal(pts[:, :3], raw[:, :3]) and (pts[:, 3] == 1).all()  # remission dropped, w = 1
-    assert set(np.unique(labels)) <= {0.0, 10.0, 40.0, 50.0, 20.0}            # instance bits stripped, moving -> static
+    # instance bits stripped; learning_map then learning_map_inv, i.e. what RangeNet++ reports (KITTIReader.cpp:189-200)
+    assert set(np.unique(labels)) == {0.0, 10.0, 20.0, 40.0, 50.0}
+    want = {0: 0, 1: 0, 10: 10, 13: 20, 16: 20, 40: 40, 50: 50, 52: 0, 60: 40, 99: 0, 252: 10, 256: 20, 257: 20, 259: 20}
+    assert all(labels[i] == want[int(lab[i] & 0xFFFF)] for i in range(1000))
+    assert kitti.remap_labels(np.array([70, 71, 72, 80, 81, 253, 254, 255, 258, 4000])).tolist() == \
+        [70, 71, 72, 80, 81, 31, 30, 32, 18, 0]
     assert (probs == 1).all()
     Tr = seq.calib["Tr"]
     assert Tr.shape == (4, 4) and Tr[3, 3] == 1 and Tr[0, 3] == 0.1
