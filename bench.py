@@ -34,18 +34,103 @@ SYMBOL = {"k6_icp_step": "k_icp_step", "k6k8_stats_radius": "k_icp_step", "k6_ic
 
 
 def hbm_traffic(label, width, height):
-    """HBM bytes per launch of the kernel behind `label`, from the committed rocprofv3 PMC passes of this very
-    command (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units,
-    FETCH_SIZE doubled for the gfx950 wide-load undercount as MI355X_MICROARCH.md prescribes).  None if absent."""
+    """HBM bytes per launch of the kernel behind `label`, from the rocprofv3 PMC passes of this very command
+    (profiles/hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs, KB units, FETCH_SIZE
+    doubled for the gfx950 wide-load undercount as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read
+    from inside the process, so the figure comes from the committed passes -- and ONLY when they were taken on the
+    kernel sources this run was built from (source hash recorded by tools/make_hbm_traffic.py); otherwise None."""
     try:
+        from semantic_suma_amd.buildinfo import kernel_source_sha
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             t = json.load(f)
-        if t.get("width") != width or t.get("height") != height:
+        if t.get("width") != width or t.get("height") != height or t.get("kernel_source_sha") != kernel_source_sha():
             return None
         k = t["kernels"].get(SYMBOL.get(label, label))
         return None if k is None else float(k["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
+
+
+def run_other_mode(args, rank, local_rank, world, coll_dev):
+    """BASELINE configs[2] (8 hypotheses per scan sharded over the ranks, one gather per scan) and configs[3] (the 11
+    KITTI odometry sequences, LPT-assigned to the ranks, several pipelines per GPU where a rank owns several)."""
+    import torch
+    import torch.distributed as dist
+    from semantic_suma_amd import core, synth
+    from semantic_suma_amd.distributed import HipEngine, gather_poses, lpt_assign, run_hypotheses, run_sequences
+    from semantic_suma_amd.types import params_with_size
+    W, H, K, Wu = args.width, args.height, args.steps, args.warmup
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    if args.mode == "hypotheses":
+        n_hyp = 8
+        p = params_with_size(W, H, max_iterations=args.icp_iterations, stopping_threshold=0.0, delta=0.0)
+        scans = [synth.generate_scan(k, n_azimuth=W, height=H)[:3] for k in range(Wu + K)]
+        eng = HipEngine(p, device=local_rank)
+        run_hypotheses(eng, scans[:Wu], n_hyp, rank, world, gather=lambda a: gather_poses(a, device=coll_dev))
+        eng2 = HipEngine(p, device=local_rank)  # fresh map for the timed run (the warm-up warmed the process, not the map)
+        barrier()
+        t0 = time.perf_counter()
+        poses, winners = run_hypotheses(eng2, scans, n_hyp, rank, world, gather=lambda a: gather_poses(a, device=coll_dev))
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            n = len(scans)
+            print(json.dumps({"metric": "scans_per_sec", "value": n / elapsed, "unit": "scans/s", "n_gpus": world, "steps": n,
+                              "warmup": Wu, "ms_per_step": 1000.0 * elapsed / n, "higher_is_better": True, "scaling": "strong",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "hypotheses_per_sec": n_hyp * (n - 1) / elapsed,
+                              "config": {"workload": f"BASELINE configs[2]: {H}x{W}, {n_hyp} ICP hypotheses per scan "
+                                                     f"({args.icp_iterations} GN iterations each) sharded over the ranks, one "
+                                                     "gather of 18 doubles per hypothesis and scan, map update with the winner "
+                                                     "on every rank",
+                                         "winners": winners[1:9], "pose_x_end": round(float(poses[-1][0, 3]), 3),
+                                         "parallelism": f"hypothesis-sharded x{world}"}}))
+        return
+    # sequences11
+    lengths_full = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # KITTI odometry 00-10
+    scale = max(1, int(os.environ.get("SUMA_SEQ_SCALE", "32")))
+    lengths = [max(4, n // scale) for n in lengths_full]
+    assign, loads = lpt_assign(lengths, world)
+    p = params_with_size(W, H)
+    mine = assign[rank]
+    cache = {s: [synth.generate_scan(1337 * (s + 1) + k, n_azimuth=W, height=H)[:3] for k in range(lengths[s])] for s in mine}
+    barrier()
+    t0 = time.perf_counter()
+    res = run_sequences(mine, lambda: core.SurfelMapping(p, device=local_rank), lambda s: cache[s],
+                        fixed_iterations=args.icp_iterations, threads=True)
+    torch.cuda.synchronize()
+    mine_s = time.perf_counter() - t0
+    ends = np.zeros((len(lengths), 16))
+    for s, (n, pose) in res.items():
+        ends[s] = pose.ravel()
+    allp = gather_poses(ends, device=coll_dev) if world > 1 else ends[None]  # the one collective: trajectory end poses
+    barrier()
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    busy = gather_poses(np.array([mine_s]), device=coll_dev)[:, 0] if world > 1 else np.array([mine_s])
+    if rank == 0:
+        total = sum(lengths)
+        print(json.dumps({"metric": "scans_per_sec", "value": total / elapsed, "unit": "scans/s", "n_gpus": world, "steps": total,
+                          "warmup": 0, "ms_per_step": 1000.0 * elapsed / total, "higher_is_better": True, "scaling": "strong",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"BASELINE configs[3]: the 11 KITTI odometry sequence lengths / {scale} "
+                                                 f"({lengths}), {H}x{W}, semantic ICP ({args.icp_iterations} GN iterations), "
+                                                 "LPT-assigned to the ranks, concurrent pipelines where a rank owns several",
+                                     "assignment": assign, "load_scans": loads,
+                                     "idle_frac_per_rank": [round(1.0 - float(b) / elapsed, 3) for b in busy],
+                                     "sequences_done": int((np.abs(allp).sum(axis=(0, 2)) > 0).sum()),
+                                     "parallelism": f"sequence-sharded x{world} (LPT)"}}))
 
 
 def main():
@@ -60,6 +145,11 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed per-kernel HIP-event pass")
     ap.add_argument("--profile-scans", type=int, default=20, help="scans of the untimed per-kernel pass")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--steady-scans", type=int, default=300,
+                    help="scans of the untimed continuation that measures the steady state (0 = skip)")
+    ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11"],
+                    help="single: BASELINE configs[1] (the bench contract); hypotheses: configs[2], 8 ICP hypotheses per scan "
+                         "sharded over the ranks; sequences11: configs[3], the 11 KITTI sequence lengths (scaled) LPT-assigned")
     ap.add_argument("--kernels-json", default=os.path.join(ROOT, "gpurun_out", "bench_kernels.json"))
     args = ap.parse_args()
 
@@ -88,7 +178,15 @@ def main():
     from semantic_suma_amd.types import params_with_size
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
-    p = params_with_size(W, H)
+    if args.mode != "single":
+        run_other_mode(args, rank, local_rank, world, coll_dev)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    kitti_dir = os.environ.get("SUMA_KITTI_DIR")  # e.g. .../sequences/00 ; absent on the build / bench machines
+    # the reference fetches label i+4 / prob i+5 for point i (Preprocessing.cpp:142-145, an offset bug that is harmless
+    # on its zero-padded network output); reproduced for parity on synthetic data, switched off for real labels
+    p = params_with_size(W, H, label_offset=0, prob_offset=0) if kitti_dir else params_with_size(W, H)
     pipe = core.SurfelMapping(p, device=local_rank)
     ctx = pipe.ctx
 
@@ -97,12 +195,12 @@ def main():
     scans = []
     t_gen = time.perf_counter()
     E = 0 if args.no_kernel_events else max(0, min(args.profile_scans, K))
-    kitti_dir = os.environ.get("SUMA_KITTI_DIR")  # e.g. .../sequences/00 ; absent on the build / bench machines
+    SS = max(0, args.steady_scans) if (rank == 0 and world == 1) else 0
     seq = None
     if kitti_dir:
         from semantic_suma_amd import kitti
         seq = kitti.Sequence(kitti_dir)
-    for k in range(Wu + K + E):
+    for k in range(Wu + K + E + SS):
         if seq is not None:
             pts, lab, prob = seq[(k0 + k) % len(seq)]
         else:
@@ -149,6 +247,21 @@ def main():
             pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
         kernels = ctx.profile_get()
     ctx.profile(0)
+    # steady state: BASELINE configs[1] is a FULL sequence; the timed region above covers its first scans, while the
+    # map is still growing.  Continue the same sequence (not timed by the driver) and time the last scans of it.
+    steady = None
+    if SS >= 40:
+        lead = SS - min(200, SS // 2)
+        for k in range(Wu + K + E, Wu + K + E + lead):
+            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+        ctx.synchronize()
+        ts = time.perf_counter()
+        for k in range(Wu + K + E + lead, Wu + K + E + SS):
+            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+        ctx.synchronize()
+        ts = time.perf_counter() - ts
+        steady = {"value": (SS - lead) / ts, "unit": "scans/s", "ms_per_step": 1000.0 * ts / (SS - lead),
+                  "scans": SS - lead, "after_scans": Wu + K + E + lead, "map_surfels": pipe.map.size()}
     if seq is None:  # synthetic trajectory: known ground truth
         gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + Wu + K - 1)
         drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
@@ -170,6 +283,9 @@ def main():
                    "points_per_scan": round(n_points), "map_surfels_end": map_size, "drift_m": round(drift, 4),
                    "parallelism": f"sequence-sharded x{world}" if world > 1 else "single GPU"},
     }
+    if steady is not None:
+        out["steady_state"] = steady
+
     def derive(ks):
         for k in ks:
             k["avg_us"] = 1000.0 * k["total_ms"] / max(k["launches"], 1)
@@ -206,13 +322,16 @@ def main():
         print(f"(untimed pass of {E} scans, every kernel group bracketed: {tot:.1f} ms of kernel time); "
               f"timed region {1000 * elapsed:.1f} ms for {K} scans; scan generation {t_gen:.1f} s", file=sys.stderr)
 
-    # ---- CPU baseline: the oracle (port of the reference path) on the first scans of the same sequence
+    # ---- CPU baseline: the oracle (port of the reference path) on the first scans of the same sequence, built
+    #      -O3 -march=native on this very host (bit-identical to the -O2 build the tests use:
+    #      tests/test_oracle_kat.py::test_native_build_is_bit_identical)
     if world == 1 and args.cpu_scans > 0:
         from oracle import pyoracle
+        variant = "native" if pyoracle.build_native() else ""
         n_cpu = min(args.cpu_scans, Wu + K)
 
         def time_oracle(threads):
-            op = pyoracle.OraclePipeline(p, threads=threads)
+            op = pyoracle.OraclePipeline(p, variant=variant, threads=threads)
             tc = time.perf_counter()
             for k in range(n_cpu):
                 pts, lab, prob = scans[k][4]
@@ -223,11 +342,12 @@ def main():
         # results: integer sums, z-buffer minima and stable compactions are order independent)
         ncores = os.cpu_count() or 1
         threads = max(1, min(ncores, 16))  # tools/oracle_scaling.py on the 256-core MI355X host: 8 -> 29, 16 -> 48, 32 -> 36, 64 -> 24 scans/s
-        sample = f"first {n_cpu} scans of the same {H}x{W} sequence through oracle/"
+        flags = "-O3 -march=native" if variant else "-O2"
+        sample = f"first {n_cpu} scans of the same {H}x{W} sequence through oracle/ (gcc {flags})"
         out["cpu_baseline"] = {"value": time_oracle(threads), "unit": "scans/s", "cores": threads, "kind": "port",
-                               "sample": f"{sample} (OpenMP, {threads} threads of {ncores} host cores)"}
+                               "sample": f"{sample}, OpenMP, {threads} threads of {ncores} host cores"}
         out["cpu_baseline_single_thread"] = {"value": time_oracle(1), "unit": "scans/s", "cores": 1, "kind": "port",
-                                             "sample": f"{sample} (one thread)"}
+                                             "sample": f"{sample}, one thread"}
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

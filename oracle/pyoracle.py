@@ -30,8 +30,19 @@ def build(force: bool = False) -> None:
         subprocess.check_call(["make", "-C", _HERE, "all"], stdout=subprocess.DEVNULL)
 
 
+def build_native() -> bool:
+    """-O3 -march=native build for bench.py's cpu_baseline leg (must be compiled on the host it runs on).
+    Returns False when no compiler is available there (the -O2 library is used instead)."""
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        return os.path.exists(os.path.join(_HERE, "libsuma_oracle_native.so"))
+    except (OSError, subprocess.CalledProcessError):
+        return False
+
+
 def lib(variant: str = ""):
-    """variant '' = deterministic-math oracle, 'libm' = glibc transcendental functions."""
+    """variant '' = deterministic-math oracle (-O2), 'native' = same sources -O3 -march=native, 'libm' = glibc
+    transcendental functions."""
     if variant in _LIBS:
         return _LIBS[variant]
     name = "libsuma_oracle.so" if not variant else f"libsuma_oracle_{variant}.so"

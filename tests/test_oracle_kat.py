@@ -176,3 +176,20 @@ def test_oracle_threads_are_bit_identical(oracle_lib):
             op.process_scan(pts, lab, prob, fixed_iterations=5)
         res.append((op.pose().tobytes(), op.ctx.map_surfels().tobytes(), op.last_stats().as_dict()))
     assert res[0] == res[1]
+
+
+def test_native_build_is_bit_identical(oracle_lib, scans):
+    """bench.py times the oracle built -O3 -march=native; it must be the same function as the -O2
+    library the parity tests use: -ffp-contract=off keeps FMA-capable hosts from fusing, integer sums are exact"""
+    if not oracle_lib.build_native():
+        pytest.skip("no compiler for the native build")
+    from semantic_suma_amd.types import params_with_size
+    p = params_with_size(360, 32)
+    a, b = oracle_lib.OraclePipeline(p), oracle_lib.OraclePipeline(p, variant="native", threads=4)
+    for k in range(5):
+        pts, lab, prob, _ = scans(k, 360, True, 32)
+        a.process_scan(pts, lab, prob, fixed_iterations=6)
+        b.process_scan(pts, lab, prob, fixed_iterations=6)
+        assert np.array_equal(a.pose(), b.pose()), f"scan {k}"
+    assert a.ctx.map_surfels().tobytes() == b.ctx.map_surfels().tobytes()
+    assert a.last_stats().as_dict() == b.last_stats().as_dict()

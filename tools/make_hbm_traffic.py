@@ -7,7 +7,11 @@ usage: make_hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collect
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from semantic_suma_amd.buildinfo import kernel_source_sha  # noqa: E402
 
 
 def per_kernel(path, counter):
@@ -27,7 +31,7 @@ def main():
         fetch_kb, write_kb = sum(fv) / len(fv), sum(wv) / len(wv)
         res[k] = {"launches": len(fv), "fetch_size_kb_raw": fetch_kb, "write_size_kb": write_kb,
                   "hbm_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0}
-    json.dump({"width": int(width), "height": int(height),
+    json.dump({"width": int(width), "height": int(height), "kernel_source_sha": kernel_source_sha(),
                "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of `python bench.py`; "
                          "bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE half-count correction)",
                "kernels": res}, open(out, "w"), indent=1)

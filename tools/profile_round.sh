@@ -1,17 +1,20 @@
 #!/bin/bash
-# One-call evidence run for profiles/ (inside a gpurun call, ~40 s of GPU time):
-#   gpurun --timeout 1800 -- 'bash tools/profile_round.sh r01d'
-# writes gpurun_out/<tag>/: pytest, bench (60 and 300 steps), rocprofv3 kernel trace + stats, the two PMC passes
-# (counter runs WITHOUT any trace domain, as the pool requires) and the 50 M-surfel stress run.
-# Afterwards, on the build machine: copy into profiles/ with the r0N_ prefix (see profiles/README.md) and run
-#   python tools/rocprof_summary.py <tag>/prof/bench_kernel_trace.csv ; python tools/make_hbm_traffic.py <fetch> <write> 2048 64 profiles/hbm_traffic.json
+# One-call evidence run for profiles/ (inside a gpurun call, ~2 min of GPU time):
+#   gpurun --timeout 1800 -- 'bash tools/profile_round.sh r02'
+# writes gpurun_out/<tag>/: pytest, bench (default and 300 steps), rocprofv3 kernel trace + stats, the two HBM PMC
+# passes and three SQ-counter passes (counter runs WITHOUT any trace domain, as the pool requires) and the
+# 50 M-surfel stress run.  Afterwards, on the build machine:  bash tools/collect_profiles.sh <tag>
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
-timeout 300 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
-timeout 300 python bench.py 2>/dev/null | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
-timeout 300 python bench.py --steps 300 --cpu-scans 0 --no-kernel-events 2>/dev/null | tail -1 > "$O/bench_300_steps.json"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o f --output-format csv -- python bench.py --cpu-scans 0 --no-kernel-events --steps 30 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o w --output-format csv -- python bench.py --cpu-scans 0 --no-kernel-events --steps 30 > /dev/null 2>&1
+B="python bench.py --cpu-scans 0 --no-kernel-events --steady-scans 0"
+timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
+timeout 400 python bench.py 2>/dev/null | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
+timeout 300 $B --steps 300 2>/dev/null | tail -1 > "$O/bench_300_steps.json"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --steady-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o f --output-format csv -- $B --steps 30 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o w --output-format csv -- $B --steps 30 > /dev/null 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES -d "$O/pmc_sq1" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq1.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d "$O/pmc_sq2" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq2.log" 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS -d "$O/pmc_sq3" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq3.log" 2>&1
 timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
-cat "$O/pytest_gpu.txt"; cut -c1-200 "$O/bench.json"
+cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; ls "$O"
