@@ -774,9 +774,9 @@ hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int 
     c->gn_iteration0 = iteration0;
     c->gn_init_pending = 1;
   } else {
-    hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->stream);
+    hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->ls);
     if (e != hipSuccess) return e;
-    k_gn_init<<<n_hyp, 64, 0, c->stream>>>(gn_buf(c, 0), c->gn_T0s, hist, iteration0);
+    k_gn_init<<<n_hyp, 64, 0, c->ls>>>(gn_buf(c, 0), c->gn_T0s, hist, iteration0);
   }
   return hipGetLastError();
 }
@@ -820,9 +820,9 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   c->gn_launch += 1;
   dim3 grid(pixel ? c->icp_blocks : 1, n_hyp);
   if (pixel)
-    k_icp_step<<<grid, ICP_THREADS, 0, c->stream>>>(g);
+    k_icp_step<<<grid, ICP_THREADS, 0, c->ls>>>(g);
   else
-    k_icp_finish<<<grid, ICP_THREADS, 0, c->stream>>>(g);
+    k_icp_finish<<<grid, ICP_THREADS, 0, c->ls>>>(g);
   return hipGetLastError();
 }
 

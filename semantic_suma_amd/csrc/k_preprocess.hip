@@ -184,11 +184,13 @@ hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_la
                              uint32_t timestamp, suma_frame* out) {
   const uint32_t P = (uint32_t)c->P;
   const int32_t W = c->pd.W, H = c->pd.H;
-  hipStream_t st = c->stream;
+  hipStream_t st = c->ls;
+  /* on the scan pipeline's side stream K1 runs while K7 / K10 of the previous scan may still use zbuf_data */
+  unsigned long long* zbuf = (st != c->stream && c->zbuf_k1) ? c->zbuf_k1 : c->zbuf_data;
   {
     ProfScope ps(c, "k1_vertexmap", 24.0 * n + 32.0 * P);
-    if (n > 0) k1_scatter<<<(n + 255) / 256, 256, 0, st>>>(d_pts, n, c->pd, c->zbuf_data);
-    k1_resolve<<<(P + 255) / 256, 256, 0, st>>>(c->zbuf_data, d_pts, d_labels, d_probs, n, c->p.label_offset,
+    if (n > 0) k1_scatter<<<(n + 255) / 256, 256, 0, st>>>(d_pts, n, c->pd, zbuf);
+    k1_resolve<<<(P + 255) / 256, 256, 0, st>>>(zbuf, d_pts, d_labels, d_probs, n, c->p.label_offset,
                                                  c->p.prob_offset, timestamp < 10 ? 1 : 0, out->map[SUMA_MAP_VERTEX],
                                                  c->eroded /* raw labels: scratch */, P);
   }

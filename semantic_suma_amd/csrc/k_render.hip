@@ -563,7 +563,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[1].inv_pose, inv_new);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -579,7 +579,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     r.so = out->map[2];
     {
       ProfScope ps(c, "k5_resolve_compose", (16.0 + 144.0) * Pm);
-      k_resolve_compose<<<(Pm + 255) / 256, 256, 0, c->stream>>>(r);
+      k_resolve_compose<<<(Pm + 255) / 256, 256, 0, c->ls>>>(r);
     }
   } else {
     /* SurfelMap.cpp:976-1018: one pass, threshold 0, then two frame copies */
@@ -591,7 +591,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[0].inv_pose, inv_old);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -602,12 +602,12 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     r.sa = out->map[2];
     {
       ProfScope ps(c, "k5_resolve", (8.0 + 48.0) * Pm);
-      k_resolve<<<(Pm + 255) / 256, 256, 0, c->stream>>>(r);
+      k_resolve<<<(Pm + 255) / 256, 256, 0, c->ls>>>(r);
     }
     size_t bytes = c->Pm * sizeof(float4);
     for (int m = 0; m < 3; ++m) {
-      hipMemcpyAsync(c->new_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->stream);
-      hipMemcpyAsync(c->old_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->stream);
+      hipMemcpyAsync(c->new_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->ls);
+      hipMemcpyAsync(c->old_frame->map[m], out->map[m], bytes, hipMemcpyDeviceToDevice, c->ls);
     }
   }
   return hipGetLastError();
@@ -632,7 +632,7 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   a.k7_enabled = fuse_k7;
   {
     ProfScope ps(c, fuse_k7 ? "k4k7_render_indexmap" : "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv);
@@ -651,7 +651,7 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   }
   {
     ProfScope ps(c, "k5_resolve", (8.0 + 32.0 + (mirror ? 64.0 : 0.0)) * (double)c->Pm);
-    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->stream>>>(r);
+    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->ls>>>(r);
   }
   return hipGetLastError();
 }
@@ -677,7 +677,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
   set_m4(a.slot[1].inv_pose, inv_new);
   {
     ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->stream>>>(a);
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv_old);
@@ -688,7 +688,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
   r.sa = nullptr;
   {
     ProfScope ps(c, "k5_resolve", (8.0 + 32.0) * (double)c->Pm);
-    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->stream>>>(r);
+    k_resolve<<<((uint32_t)c->Pm + 255) / 256, 256, 0, c->ls>>>(r);
   }
   return hipGetLastError();
 }

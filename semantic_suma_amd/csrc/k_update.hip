@@ -774,7 +774,7 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.cx = cx;
   a.cy = cy;
   a.extent = extent;
-  hipStream_t st = c->stream;
+  hipStream_t st = c->ls;
   const uint32_t gridS = stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
   a.pose_idx = c->timestamp;
   a.write_pose = 0;
@@ -840,18 +840,18 @@ __global__ void k_clear_keys(unsigned long long* z, uint32_t n) {
 }
 hipError_t launch_clear_index_zbuf(suma_ctx* c) {
   uint32_t P = (uint32_t)c->P;
-  k_clear_keys<<<(P + 255) / 256, 256, 0, c->stream>>>(c->zbuf_data, P);
+  k_clear_keys<<<(P + 255) / 256, 256, 0, c->ls>>>(c->zbuf_data, P);
   return hipGetLastError();
 }
 
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n) {
   if (n == 0) return hipSuccess;
-  k_set_poses<<<(n + 255) / 256, 256, 0, c->stream>>>(c->poses, c->poses_inv, d_src, first, n);
+  k_set_poses<<<(n + 255) / 256, 256, 0, c->ls>>>(c->poses, c->poses_inv, d_src, first, n);
   return hipGetLastError();
 }
 hipError_t launch_fill_identity_poses(suma_ctx* c) {
   uint32_t n = c->p.max_poses;
-  k_identity_poses<<<(n + 255) / 256, 256, 0, c->stream>>>(c->poses, c->poses_inv, n);
+  k_identity_poses<<<(n + 255) / 256, 256, 0, c->ls>>>(c->poses, c->poses_inv, n);
   return hipGetLastError();
 }
 
@@ -994,7 +994,7 @@ hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float 
   a.cy = cy;
   a.extent = extent;
   ProfScope ps(c, "k12_extract_submap", 64.0 * (double)c->known_surfels);
-  k12_extract<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + K12_ITEMS - 1) / K12_ITEMS), SUMA_TILE, 0, c->stream>>>(a);
+  k12_extract<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + K12_ITEMS - 1) / K12_ITEMS), SUMA_TILE, 0, c->ls>>>(a);
   return hipGetLastError();
 }
 
@@ -1021,8 +1021,8 @@ __global__ void k_append_commit(DevState* ds, const CacheSlot* slots, uint32_t s
 }
 
 hipError_t launch_append_cached(suma_ctx* c, uint32_t slot) {
-  k_append_cached<<<1024, 256, 0, c->stream>>>(c->surfels[c->cur], c->cache_arena, c->ds, c->cache_slots, slot,
+  k_append_cached<<<1024, 256, 0, c->ls>>>(c->surfels[c->cur], c->cache_arena, c->ds, c->cache_slots, slot,
                                                c->p.max_surfels);
-  k_append_commit<<<1, 1, 0, c->stream>>>(c->ds, c->cache_slots, slot, c->p.max_surfels);
+  k_append_commit<<<1, 1, 0, c->ls>>>(c->ds, c->cache_slots, slot, c->p.max_surfels);
   return hipGetLastError();
 }

@@ -112,15 +112,17 @@ int prof_begin(suma_ctx* c, const char* name, double bytes, uint32_t launches) {
       return -1;
     }
   }
-  hipEventRecord(ev.a, c->stream);
+  ev.stream = c->ls;
+  hipEventRecord(ev.a, ev.stream);
   c->prof_events.push_back(ev);
   return (int)c->prof_events.size() - 1;
 }
-void prof_end(suma_ctx* c, int token) { hipEventRecord(c->prof_events[token].b, c->stream); }
+void prof_end(suma_ctx* c, int token) { hipEventRecord(c->prof_events[token].b, c->prof_events[token].stream); }
 
 static void prof_collect(suma_ctx* c) {
   if (c->prof_events.empty()) return;
   hipStreamSynchronize(c->stream);
+  if (c->side_stream) hipStreamSynchronize(c->side_stream);
   for (auto& ev : c->prof_events) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
@@ -246,6 +248,9 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   c->scan_labels = c->scan_probs = nullptr;
   c->icp_current = c->icp_model = nullptr;
   c->obj_set = false;
+  c->side_stream = nullptr;
+  c->sync_flags = nullptr;
+  c->zbuf_k1 = nullptr;
   derive(c);
   c->P = (size_t)params->data_width * params->data_height;
   c->Pm = (size_t)params->model_width * params->model_height;
@@ -253,6 +258,10 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   auto body = [&]() -> int {
     CK(hipSetDevice(hip_device));
     CK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->ls = c->stream;
+    CK(hipMalloc((void**)&c->sync_flags, 16 * sizeof(uint32_t)));
+    CK(hipMemsetAsync(c->sync_flags, 0, 16 * sizeof(uint32_t), c->stream));
+    c->pre_seq = 0;
     const size_t P = c->P, Pm = c->Pm;
     CK(hipMalloc((void**)&c->zbuf_data, P * 8));
     CK(hipMemsetAsync(c->zbuf_data, 0xFF, P * 8, c->stream));
@@ -336,6 +345,10 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->side_stream) {
+    hipStreamSynchronize(c->side_stream);
+    hipStreamDestroy(c->side_stream);
+  }
   for (auto& ev : c->prof_events) {
     hipEventDestroy(ev.a);
     hipEventDestroy(ev.b);
@@ -344,7 +357,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
   void* dev[] = {c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
-                 c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs};
+                 c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs, c->sync_flags, c->zbuf_k1};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_ds) hipHostFree(c->h_ds);
@@ -370,6 +383,7 @@ extern "C" int suma_set_params(suma_ctx* c, const suma_params* p) {
 }
 extern "C" int suma_synchronize(suma_ctx* c) {
   if (!c) return SUMA_ERR_INVALID;
+  if (c->side_stream) CK(hipStreamSynchronize(c->side_stream));
   CK(hipStreamSynchronize(c->stream));
   return SUMA_OK;
 }
@@ -484,9 +498,9 @@ static int stage_scan(suma_ctx* c, const suma_float4* points, const float* label
     c->scan_cap = cap;
   }
   if (n == 0) return SUMA_OK;
-  CK(hipMemcpyAsync(c->scan_points, points, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->stream));
-  if (labels) CK(hipMemcpyAsync(c->scan_labels, labels, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
-  if (probs) CK(hipMemcpyAsync(c->scan_probs, probs, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(c->scan_points, points, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, c->ls));
+  if (labels) CK(hipMemcpyAsync(c->scan_labels, labels, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->ls));
+  if (probs) CK(hipMemcpyAsync(c->scan_probs, probs, (size_t)n * sizeof(float), hipMemcpyHostToDevice, c->ls));
   return SUMA_OK;
 }
 
@@ -1059,6 +1073,18 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
     return SUMA_ERR_HIP;
   }
   memset(s->h_res, 0, 3 * sizeof(HostResult));
+  /* side stream for work off the critical path of a scan (k_sync.hip); SUMA_NO_SIDE_STREAM=1 keeps everything on
+   * the ctx stream (A/B measurements) */
+  if (!getenv("SUMA_NO_SIDE_STREAM")) {
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipMalloc((void**)&c->zbuf_k1, c->P * 8) != hipSuccess ||
+        hipMemsetAsync(c->zbuf_k1, 0xFF, c->P * 8, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+      g_create_error = "side stream setup failed";
+      suma_pipeline_destroy(s);
+      return SUMA_ERR_HIP;
+    }
+  }
   s->res_seq = 0;
   s->stats_pending = false;
   s->stats_slot = 0;
@@ -1280,16 +1306,34 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   return SUMA_OK;
 }
 
-extern "C" int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                                                 const float* d_probs, uint32_t n, int32_t fixed_iterations) {
+/* upload_done: optional event on another stream that the scan's device buffers depend on (device-side ingest) */
+int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                               const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done) {
   if (!s || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
   suma_ctx* c = s->c;
   /* initialize(), SurfelMapping.cpp:323-331 */
   std::swap(s->last_frame, s->current_frame);
   std::swap(s->last_model, s->current_model);
-  /* preprocess(), :342-358 */
-  int r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
-  if (r) return r;
+  /* preprocess(), :342-358.  K1-K3 of this scan go to the side stream: the host is ahead of the GPU here (the
+   * surfel passes of the previous scan are still running on the ctx stream), so they overlap that tail instead of
+   * queueing behind it.  Buffers: the frame written here was last read by work the host has already waited for (the
+   * previous scan's minimisation result is behind it in stream order), K1 has its own z-buffer.  The ctx stream
+   * continues behind a gate that waits for the side stream's signal (k_sync.hip). */
+  int r;
+  if (c->side_stream) {
+    if (upload_done) HIP_TRY(c, hipStreamWaitEvent(c->side_stream, upload_done, 0));
+    c->ls = c->side_stream;
+    r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
+    c->ls = c->stream;
+    if (r) return r;
+    c->pre_seq += 1;
+    HIP_TRY(c, launch_signal(c, c->side_stream, 0, c->pre_seq));
+    HIP_TRY(c, launch_gate(c, c->stream, 0, c->pre_seq));
+  } else {
+    if (upload_done) HIP_TRY(c, hipStreamWaitEvent(c->stream, upload_done, 0));
+    r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
+    if (r) return r;
+  }
   float po[16], pn[16];
   cast_f(s->pose_old, po);
   cast_f(s->pose_new, pn);
@@ -1310,12 +1354,22 @@ extern "C" int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_fl
   return SUMA_OK;
 }
 
+extern "C" int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                                                 const float* d_probs, uint32_t n, int32_t fixed_iterations) {
+  return pipeline_process_scan_impl(s, d_points, d_labels, d_probs, n, fixed_iterations, nullptr);
+}
+
 extern "C" int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, const float* labels,
                                           const float* probs, uint32_t n, int32_t fixed_iterations) {
   if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
-  int r = stage_scan(s->c, points, labels, probs, n);
+  suma_ctx* c = s->c;
+  /* blocking hand-over of a pageable host scan (the reference's glBufferData in Frame::points.assign,
+   * Preprocessing.cpp:123-125): staged on the stream the preprocessing runs on; the overlapped path is
+   * suma_pipeline_prefetch_scan / process_prefetched (suma_ingest.hip) */
+  if (c->side_stream) c->ls = c->side_stream;
+  int r = stage_scan(c, points, labels, probs, n);
+  c->ls = c->stream;
   if (r) return r;
-  return suma_pipeline_process_scan_device(s, (const suma_float4*)s->c->scan_points,
-                                           labels ? s->c->scan_labels : nullptr, probs ? s->c->scan_probs : nullptr, n,
-                                           fixed_iterations);
+  return suma_pipeline_process_scan_device(s, (const suma_float4*)c->scan_points, labels ? c->scan_labels : nullptr,
+                                           probs ? c->scan_probs : nullptr, n, fixed_iterations);
 }

@@ -58,6 +58,7 @@ extern "C" int suma_dist_comm_create(const char id[SUMA_DIST_ID_BYTES], int worl
   c->d_send = c->d_recv = c->h_buf = nullptr;
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
+  (void)hipGetLastError(); /* RCCL reports a stale, already handled HIP error of the calling thread as its own */
   ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank); /* on the calling thread's current HIP device */
   if (r != ncclSuccess) {
     g_dist_error = std::string("ncclCommInitRank: ") + ncclGetErrorString(r);

@@ -204,11 +204,11 @@ extern "C" int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_
     }
   }
   const uint32_t n = q->n;
-  HIP_TRY(c, hipStreamWaitEvent(c->stream, q->uploaded, 0));
-  int r = suma_pipeline_process_scan_device(s, (const suma_float4*)q->device,
-                                            q->labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
-                                            q->probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n,
-                                            fixed_iterations);
+  /* the stream that runs the scan's preprocessing waits for the upload (device-side dependency) */
+  int r = pipeline_process_scan_impl(s, (const suma_float4*)q->device,
+                                     q->labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
+                                     q->probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n,
+                                     fixed_iterations, q->uploaded);
   const hipError_t ec = hipEventRecord(q->consumed, c->stream);
   {
     std::lock_guard<std::mutex> lk(g->mu);

@@ -85,6 +85,7 @@ struct suma_frame {
 
 struct ProfEvent {
   hipEvent_t a, b;
+  hipStream_t stream; /* the launch stream the pair brackets */
   int id;
   double bytes;
   uint32_t launches; /* kernel launches bracketed by this event pair (a chain of identical launches) */
@@ -93,7 +94,11 @@ struct ProfEvent {
 struct suma_ctx {
   suma_params p;
   int device;
-  hipStream_t stream;
+  hipStream_t stream;      /* the ctx stream: everything the C-ABI promises to order */
+  hipStream_t ls;          /* stream the launchers enqueue on: == stream, except while the scan pipeline enqueues side work */
+  hipStream_t side_stream; /* scan pipeline only: work that is off the critical path of a scan (next scan's preprocessing) */
+  uint32_t* sync_flags;    /* device: sequence words of the in-memory stream hand-offs (k_sync.hip) */
+  uint32_t pre_seq;        /* preprocessing hand-offs issued so far */
   std::string err;
 
   proj_t pd, pm; /* data / model projection */
@@ -101,7 +106,8 @@ struct suma_ctx {
   size_t P, Pm;
 
   /* preprocessing scratch */
-  unsigned long long* zbuf_data; /* P keys: K1 and K7 */
+  unsigned long long* zbuf_data; /* P keys: K7 (and K1 outside the scan pipeline's side stream) */
+  unsigned long long* zbuf_k1;   /* P keys: K1 of the scan pipeline -- preprocessing of scan t+1 overlaps K7 / K10 of scan t */
   float4* eroded;                /* P: raw labels of K1 (scratch between k1_resolve and the fused K2/K3) */
   float4* scan_points;           /* staging for host scans */
   float *scan_labels, *scan_probs;
@@ -210,6 +216,8 @@ struct suma_pipeline {
   struct Ingest* ingest; /* pinned double-buffered scan staging + copy stream + ingest thread (suma_ingest.hip) */
 };
 
+int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
+                               uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done);
 /* suma_ingest.hip */
 void ingest_destroy(suma_pipeline* s);
 
@@ -260,6 +268,12 @@ hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uin
 hipError_t launch_fill_identity_poses(suma_ctx* c);
 hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent);
 hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
+
+/* k_sync.hip: in-memory hand-offs between the ctx stream and the side stream.  A runtime event dependency between two
+ * HIP streams costs ~10 us of stall on this platform (tools/xstream.hip: ping-pong 42 us vs 22 us for the same two
+ * 10 us kernels on one stream); a one-wave gate kernel that polls a sequence word costs ~2 us. */
+hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
+hipError_t launch_gate(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
 
 /* host helper shared by api + pipeline */
 void rigid_inverse_f(const float* m, float* out);

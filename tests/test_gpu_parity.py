@@ -715,32 +715,48 @@ def test_async_ingest_equals_resident_scans(hip):
         a.prefetchScan(*scans_[2])  # both slots staged
 
 
-def test_gather_poses_rccl_world_1(hip):
+_GATHER_SCRIPT = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+from semantic_suma_amd import core
+from semantic_suma_amd.types import params_with_size
+D = C.CDLL(os.path.join(os.path.dirname(core.LIB_PATH), "libsuma_hip_dist.so"))
+vp = C.c_void_p
+D.suma_dist_unique_id.argtypes = [vp]
+D.suma_dist_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+D.suma_dist_comm_destroy.argtypes = [vp]
+D.suma_gather_poses.argtypes = [vp, vp, vp, vp]
+D.suma_gather.argtypes = [vp, vp, vp, C.c_uint32, vp]
+D.suma_dist_last_error.restype = C.c_char_p
+D.suma_dist_last_error.argtypes = [vp]
+ctx = core.Context(params_with_size(900))
+uid = C.create_string_buffer(128)
+assert D.suma_dist_unique_id(uid) == 0, D.suma_dist_last_error(None)
+comm = vp()
+assert D.suma_dist_comm_create(uid, 1, 0, C.byref(comm)) == 0, D.suma_dist_last_error(None)
+pose = np.arange(16, dtype=np.float64) + 0.5
+out = np.zeros(16, dtype=np.float64)
+assert D.suma_gather_poses(ctx.h, comm, pose.ctypes.data, out.ctypes.data) == 0, D.suma_dist_last_error(comm)
+assert np.array_equal(out, pose)
+payload = np.linspace(0, 1, 21)
+out2 = np.zeros(21)
+assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 21, out2.ctypes.data) == 0 and np.array_equal(out2, payload)
+assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 65, out2.ctypes.data) != 0  # over the 64-double limit
+D.suma_dist_comm_destroy(comm)
+print("gather ok")
+"""
+
+
+def test_gather_poses_rccl_world_1():
     """libsuma_hip_dist.so: the C-ABI gather (RCCL all-gather on the ctx stream).  A 1-GPU box can only host a
-    communicator of size 1 (RCCL refuses two ranks on one device); the N-rank path is exercised by bench.py --gpus N."""
-    import ctypes as C
+    communicator of size 1 (RCCL refuses two ranks on one device); the N-rank path is exercised by bench.py --gpus N.
+    Runs in a fresh interpreter, like the C++ host it is meant for: a process that has already imported torch carries
+    torch's bundled ROCm runtime next to the system one, and RCCL must initialise against the runtime the HIP
+    library uses."""
     import os
-    path = os.path.join(os.path.dirname(hip.LIB_PATH), "libsuma_hip_dist.so")
-    D = C.CDLL(path)
-    vp = C.c_void_p
-    D.suma_dist_unique_id.argtypes = [vp]
-    D.suma_dist_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
-    D.suma_dist_comm_destroy.argtypes = [vp]
-    D.suma_gather_poses.argtypes = [vp, vp, vp, vp]
-    D.suma_gather.argtypes = [vp, vp, vp, C.c_uint32, vp]
-    D.suma_dist_last_error.restype = C.c_char_p
-    D.suma_dist_last_error.argtypes = [vp]
-    ctx = hip.Context(params_with_size(900))
-    uid = C.create_string_buffer(128)
-    assert D.suma_dist_unique_id(uid) == 0, D.suma_dist_last_error(None)
-    comm = vp()
-    assert D.suma_dist_comm_create(uid, 1, 0, C.byref(comm)) == 0, D.suma_dist_last_error(None)
-    pose = np.arange(16, dtype=np.float64) + 0.5
-    out = np.zeros(16, dtype=np.float64)
-    assert D.suma_gather_poses(ctx.h, comm, pose.ctypes.data, out.ctypes.data) == 0, D.suma_dist_last_error(comm)
-    assert np.array_equal(out, pose)
-    payload = np.linspace(0, 1, 21)
-    out2 = np.zeros(21)
-    assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 21, out2.ctypes.data) == 0 and np.array_equal(out2, payload)
-    assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 65, out2.ctypes.data) != 0  # over the 64-double limit
-    D.suma_dist_comm_destroy(comm)
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _GATHER_SCRIPT, root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "gather ok" in out.stdout, out.stderr[-2000:]
