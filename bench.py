@@ -219,8 +219,8 @@ def main():
     for k in range(Wu):
         pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
     # timed region: only the Gauss-Newton chain (the dominant kernel) is bracketed by HIP events -- one event
-    # pair per chain of identical launches, i.e. two event records per scan
-    ctx.profile(2)
+    # pair per chain of identical launches, on every 4th scan (an event record costs the stream a ~6 us bubble)
+    ctx.profile(3)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
@@ -302,7 +302,8 @@ def main():
                            "traffic": hbm_traffic(dom["name"], W, H),
                            "avg_launch_us": dom["avg_us"], "bytes_per_launch": dom["bytes_per_launch"],
                            "launches": dom["launches"],
-                           "share_of_timed_region": dom["total_ms"] / (1000.0 * elapsed)}
+                           "launches_in_timed_region": K * args.icp_iterations,
+                           "share_of_timed_region": dom["avg_us"] * K * args.icp_iterations / (1e6 * elapsed)}
         if kernels:
             out["roofline"]["kernel_time_share"] = next(
                 (k["total_ms"] for k in kernels if k["name"] == dom["name"]), 0.0) / sum(k["total_ms"] for k in kernels)

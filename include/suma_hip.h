@@ -217,7 +217,7 @@ int suma_device_download(suma_ctx* ctx, void* host_dst, const void* d_src, uint6
 /* ---- per-kernel timing (rv::Stopwatch / SurfelMapping::Stats, SurfelMapping.cpp:183-207):
  *      on = 1: every kernel group is bracketed by HIP events on the ctx stream; on = 2: only the
  *      Gauss-Newton chain (the kernel with the largest share of GPU time), which costs two event
- *      records per scan and leaves the throughput undisturbed; on = 0: off.
+ *      records per scan (each costs the stream a ~6 us bubble); on = 3: the same on every 4th scan; on = 0: off.
  *      suma_profile_get fills up to cap entries, returns the number of distinct kernels. */
 typedef struct suma_kernel_time {
   char name[48];

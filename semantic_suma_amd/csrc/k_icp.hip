@@ -329,54 +329,62 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     for (uint32_t h = blockIdx.y; h < g.zero_hyp; h += gridDim.y)
       g.pzero[(size_t)h * ICP_RECORDS * SUMA_ACC_WORDS + threadIdx.x] = 0;
 
+  /* Everything this block needs from memory before it can compute is requested up front and TOGETHER -- the
+   * previous launch's accumulator records (wave 0: four words per lane), the pose columns of lanes 0..15, this
+   * lane's data-frame texels -- so that the prologue pays one cold round trip, not a chain of them: none of these
+   * addresses depends on the state words read below.  (A launch that finds its chain finished has loaded in vain;
+   * it exits right after.) */
+  const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * ICP_RECORDS * SUMA_ACC_WORDS;
+  long long rec[ICP_RECORDS / 2] = {0, 0, 0, 0};
+  if (threadIdx.x < 64 && !g.init) {
+    /* lane L of wave 0: word L & 31 of records (L >> 5) * 4 .. + 3 */
+#pragma unroll
+    for (int q = 0; q < ICP_RECORDS / 2; ++q) rec[q] = pin[((threadIdx.x >> 5) * (ICP_RECORDS / 2) + q) * SUMA_ACC_WORDS + (threadIdx.x & 31)];
+  }
+  /* lanes 0..15 form one element each of exp(delta) * pose_ at the end of the prologue: their column of the
+   * current pose (and their own element, for launches that do not move the pose) comes straight from HBM */
+  double tk_col[4] = {0.0, 0.0, 0.0, 0.0}, tk_self = 0.0;
+  if (threadIdx.x < 16 && !g.init) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) tk_col[q] = gin->Tk[4 * (threadIdx.x >> 2) + q];
+    tk_self = gin->Tk[threadIdx.x];
+  }
+  /* data-frame loads of this lane's first pixel do not depend on the pose */
+  const uint32_t pix0 = blockIdx.x * ICP_THREADS + threadIdx.x;
+  float4 vd4 = f4(0, 0, 0, 0), nd4 = vd4, sd4 = vd4;
+  if (PIXEL && pix0 < a.P) {
+    vd4 = a.Vd[pix0];
+    nd4 = a.Nd[pix0];
+    sd4 = a.Sd[pix0];
+  }
+
   /* wave-uniform state (scalar loads), or the start state of a fresh chain */
   const uint32_t done_in = g.init ? 0u : gin->done, pending = g.init ? 0u : gin->pending;
   uint32_t iteration = g.init ? g.iteration0 : gin->iteration;
   double Tk[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) Tk[i] = g.init ? g.T0.m[i] : gin->Tk[i];
-
-  /* lanes 0..15 form one element each of exp(delta) * pose_ at the end of the prologue: their column of the
-   * current pose (and their own element, for launches that do not move the pose) comes straight from HBM */
-  double tk_col[4] = {0.0, 0.0, 0.0, 0.0}, tk_self = 0.0;
-  if (threadIdx.x < 16 && pending) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) tk_col[q] = gin->Tk[4 * (threadIdx.x >> 2) + q];
-    tk_self = gin->Tk[threadIdx.x];
-  }
-
-  /* data-frame loads of this lane's first pixel do not depend on the pose: issue them now so that
-   * their latency overlaps the prologue */
-  const uint32_t pix0 = blockIdx.x * ICP_THREADS + threadIdx.x;
   const bool want_px = PIXEL && !(done_in && !pending);
-  float4 vd4 = f4(0, 0, 0, 0), nd4 = vd4, sd4 = vd4;
-  if (want_px && pix0 < a.P) {
-    vd4 = a.Vd[pix0];
-    nd4 = a.Nd[pix0];
-    sd4 = a.Sd[pix0];
-  }
 
   float prefetch_sink = 0.0f;
   uint32_t done = done_in;
   if (pending) {
-    /* ---- total of the previous launch's accumulator records: one load per lane ---- */
-    const long long* __restrict__ pin = g.pin + (size_t)blockIdx.y * ICP_RECORDS * SUMA_ACC_WORDS;
-    if (threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) s_tot[threadIdx.x >> 5][threadIdx.x & 31] = pin[threadIdx.x];
-    __syncthreads();
-    if (threadIdx.x < SUMA_ACC_WORDS) {
-      /* 32 lanes fold the records, remove the fixed-point bias and convert: word w of the totals and its
-       * value in double land in LDS */
-      long long sum = 0;
-#pragma unroll
-      for (int q = 0; q < ICP_RECORDS; ++q) sum += s_tot[q][threadIdx.x];
+    if (threadIdx.x < 64) {
+      /* ---- wave 0 totals the previous launch's accumulator records in registers (no LDS round trip, no block
+       *      barrier: everything up to the pose broadcast below stays inside this wave, whose LDS traffic is in
+       *      order), removes the fixed-point bias and converts: word w of the totals and its value in double land
+       *      in LDS for the solve ---- */
+      long long sum = (rec[0] + rec[1]) + (rec[2] + rec[3]);
+      sum += shfl_xor_ll(sum, 32);
       const long long n_valid = readlane_ll(sum, 29), n_outlier = readlane_ll(sum, 30), n_inlier = n_valid - n_outlier;
-      const int w = threadIdx.x;
+      const int w = threadIdx.x & 31;
       if (w < 27 || w == 28) sum -= n_inlier * MAGIC_BITS;
       if (w == 27) sum -= n_valid * MAGIC_BITS;
-      s_wave[0][w] = sum;
-      s_val[w] = (double)sum * (1.0 / SUMA_ACC_SCALE);
+      if (threadIdx.x < SUMA_ACC_WORDS) {
+        s_wave[0][w] = sum;
+        s_val[w] = (double)sum * (1.0 / SUMA_ACC_SCALE);
+      }
     }
-    __syncthreads();
     if (PIXEL && threadIdx.x >= 64 && want_px && pix0 < a.P && (vd4.w + nd4.w) > 1.5f) {
       /* The seven waves that now only wait for lane 0's solve warm the caches for their own pixel:
        * the model texels move by a fraction of a texel per iteration, so touching the lines the

@@ -36,3 +36,9 @@ hipError_t launch_gate(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq)
   k_gate<<<1, 64, 0, st>>>(c->sync_flags + word, seq, &c->ds->overflow);
   return hipGetLastError();
 }
+hipError_t flush_gate(suma_ctx* c) {
+  if (!c->gate_pending) return hipSuccess;
+  const uint32_t seq = c->gate_pending;
+  c->gate_pending = 0;
+  return launch_gate(c, c->stream, 0, seq);
+}

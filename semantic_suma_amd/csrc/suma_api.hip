@@ -139,7 +139,7 @@ static void prof_collect(suma_ctx* c) {
 extern "C" int suma_profile_enable(suma_ctx* c, int on) {
   if (!c) return SUMA_ERR_INVALID;
   prof_collect(c);
-  c->profiling = on < 0 ? 0 : (on > 2 ? 1 : on);
+  c->profiling = on < 0 ? 0 : (on > 3 ? 1 : on);
   if (c->prof_filter.empty()) c->prof_filter = "k6_icp_step";
   return SUMA_OK;
 }
@@ -242,6 +242,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   c->p = *params;
   c->device = hip_device;
   c->profiling = 0;
+  c->prof_tick = 0;
   c->epoch = 0;
   c->scan_cap = 0;
   c->scan_points = nullptr;
@@ -262,6 +263,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->sync_flags, 16 * sizeof(uint32_t)));
     CK(hipMemsetAsync(c->sync_flags, 0, 16 * sizeof(uint32_t), c->stream));
     c->pre_seq = 0;
+    c->gate_pending = 0;
     const size_t P = c->P, Pm = c->Pm;
     CK(hipMalloc((void**)&c->zbuf_data, P * 8));
     CK(hipMemsetAsync(c->zbuf_data, 0xFF, P * 8, c->stream));
@@ -610,6 +612,7 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
 static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history) {
   const uint32_t max_iter = c->p.max_iterations;
   const uint32_t iter_arg = max_iter > 0 ? max_iter : 0xffffffffu;
+  if (c->gate_pending) CK(flush_gate(c)); /* the chain reads the frame the side stream preprocessed (k_sync.hip) */
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
@@ -764,6 +767,7 @@ static int update_active_submaps(suma_ctx* c, const float* pose) {
 }
 
 extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_frame* frame) {
+  if (c && c->gate_pending) CK(flush_gate(c));
   if (!c || !pose || !frame) return SUMA_ERR_INVALID;
   if (frame->width != c->p.data_width || frame->height != c->p.data_height)
     return fail(c, SUMA_ERR_INVALID, "suma_map_update: frame size differs from data_width x data_height");
@@ -1328,7 +1332,7 @@ int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, co
     if (r) return r;
     c->pre_seq += 1;
     HIP_TRY(c, launch_signal(c, c->side_stream, 0, c->pre_seq));
-    HIP_TRY(c, launch_gate(c, c->stream, 0, c->pre_seq));
+    c->gate_pending = c->pre_seq; /* the first reader of the frame on the ctx stream issues the gate (flush_gate) */
   } else {
     if (upload_done) HIP_TRY(c, hipStreamWaitEvent(c->stream, upload_done, 0));
     r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);

@@ -99,6 +99,7 @@ struct suma_ctx {
   hipStream_t side_stream; /* scan pipeline only: work that is off the critical path of a scan (next scan's preprocessing) */
   uint32_t* sync_flags;    /* device: sequence words of the in-memory stream hand-offs (k_sync.hip) */
   uint32_t pre_seq;        /* preprocessing hand-offs issued so far */
+  uint32_t gate_pending;   /* != 0: the ctx stream has not yet waited for this preprocessing hand-off (flush_gate) */
   std::string err;
 
   proj_t pd, pm; /* data / model projection */
@@ -171,7 +172,8 @@ struct suma_ctx {
   std::vector<std::pair<int32_t, int32_t>> extraction;        /* pending tiles, used as a stack */
 
   /* profiling */
-  int profiling; /* 0 off, 1 every kernel group, 2 only the group named prof_filter */
+  int profiling; /* 0 off, 1 every kernel group, 2 only the group named prof_filter, 3 every 4th occurrence of that group */
+  uint32_t prof_tick;
   std::string prof_filter;
   std::vector<ProfEvent> prof_events;
   std::vector<hipEvent_t> prof_pool;
@@ -237,7 +239,14 @@ struct ProfScope {
   suma_ctx* c;
   int tok;
   ProfScope(suma_ctx* c_, const char* name, double bytes, uint32_t launches = 1)
-      : c(c_), tok((c_->profiling == 1 || (c_->profiling == 2 && c_->prof_filter == name)) ? prof_begin(c_, name, bytes, launches) : -1) {}
+      : c(c_), tok(wanted(c_, name) ? prof_begin(c_, name, bytes, launches) : -1) {}
+  static bool wanted(suma_ctx* c, const char* name) {
+    if (c->profiling == 1) return true;
+    if (c->profiling < 2 || c->prof_filter != name) return false;
+    /* an event record is a barrier + signal packet: ~6 us of bubble in front of the kernel behind it (rocprofv3
+     * timeline).  Mode 3 samples one occurrence in four so that the measurement costs the measured run < 1 % */
+    return c->profiling == 2 || (c->prof_tick++ & 3u) == 0;
+  }
   ~ProfScope() {
     if (tok >= 0) prof_end(c, tok);
   }
@@ -274,6 +283,8 @@ hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
  * 10 us kernels on one stream); a one-wave gate kernel that polls a sequence word costs ~2 us. */
 hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
 hipError_t launch_gate(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
+/* makes the ctx stream wait for the pending preprocessing hand-off (one-wave gate kernel) */
+hipError_t flush_gate(suma_ctx* c);
 
 /* host helper shared by api + pipeline */
 void rigid_inverse_f(const float* m, float* out);
