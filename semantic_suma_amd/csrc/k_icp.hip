@@ -141,6 +141,46 @@ __device__ __forceinline__ int word_of_lane(int lane) {
          ((lane >> 1) & 1);
 }
 
+/* The same butterfly for 16 words: halving stages 8 / 4 (lane swaps), 2 / 1 (xor 8, xor 4), then the two lane bits
+ * that select no word are summed out.  Afterwards lane L holds the wave total of word
+ * ((L>>5)&1)*8 + ((L>>4)&1)*4 + ((L>>3)&1)*2 + ((L>>2)&1)  (every word on four lanes). */
+template <int H, bool SWAP32>
+__device__ __forceinline__ void reduce16_stage_swap(long long (&a)[16]) {
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    unsigned int x_lo = (unsigned int)a[i], x_hi = (unsigned int)(a[i] >> 32);
+    unsigned int y_lo = (unsigned int)a[i + H], y_hi = (unsigned int)(a[i + H] >> 32);
+    auto lo = SWAP32 ? __builtin_amdgcn_permlane32_swap(x_lo, y_lo, false, false)
+                     : __builtin_amdgcn_permlane16_swap(x_lo, y_lo, false, false);
+    auto hi = SWAP32 ? __builtin_amdgcn_permlane32_swap(x_hi, y_hi, false, false)
+                     : __builtin_amdgcn_permlane16_swap(x_hi, y_hi, false, false);
+    long long p = (long long)(((unsigned long long)hi[0] << 32) | lo[0]);
+    long long q = (long long)(((unsigned long long)hi[1] << 32) | lo[1]);
+    a[i] = p + q;
+  }
+}
+template <int H, int MASK>
+__device__ __forceinline__ void reduce16_stage(long long (&a)[16], int lane) {
+  const bool upper = (lane & MASK) != 0;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    long long keep = upper ? a[i + H] : a[i];
+    long long send = upper ? a[i] : a[i + H];
+    a[i] = keep + shfl_xor_ll(send, MASK);
+  }
+}
+__device__ __forceinline__ long long wave_reduce16(long long (&a)[16], int lane) {
+  reduce16_stage_swap<8, true>(a);
+  reduce16_stage_swap<4, false>(a);
+  reduce16_stage<2, 8>(a, lane);
+  reduce16_stage<1, 4>(a, lane);
+  long long t = a[0] + shfl_xor_ll(a[0], 2);
+  return t + shfl_xor_ll(t, 1);
+}
+__device__ __forceinline__ int word16_of_lane(int lane) {
+  return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);
+}
+
 __device__ __forceinline__ long long readlane_ll(long long v, int src) {
   const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, src);
   const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), src);
@@ -569,9 +609,11 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) T[i] = (float)Tk[i]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
 
-  long long acc[SUMA_ACC_WORDS];
-#pragma unroll
-  for (int i = 0; i < SUMA_ACC_WORDS; ++i) acc[i] = 0;
+  /* Per trip the 32 terms of a pixel are formed and wave-reduced in two halves of 16 words: a lane never holds more
+   * than 16 int64 terms (32 VGPRs instead of 64), and what it carries from trip to trip is the wave total of ONE word
+   * per half.  The sums are exact integers, so reducing per trip instead of once changes no bit. */
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  long long totA = 0, totB = 0; /* wave totals of word word16_of_lane(lane) and 16 + word16_of_lane(lane) */
   double fx_scale, fx_magic;
   fix_consts(&fx_scale, &fx_magic);
 
@@ -622,6 +664,9 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         pair = e_m > 1.5f;
       }
     }
+    float J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wgt = 0.f, wr = 0.f, wr2 = 0.f;
+    bool is_inlier = false;
+    const bool valid_px = true; /* this trip processes a pixel of the image (the loop bound guarantees it) */
     if (pair) {
       v3 v_m = xyz(vm4), n_m = xyz(nm4);
       bool inlier = true;
@@ -650,34 +695,59 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         else
           weight *= data_prob;
       }
-      float wr2 = (weight * residual) * residual;
-      acc[27] += fix_bits(wr2, fx_scale, fx_magic);
-      acc[29] += 1;
-      if (inlier) {
-        const float J[6] = {n_m.x, n_m.y, n_m.z, cp.x, cp.y, cp.z};
-        int k = 0;
+      wr2 = (weight * residual) * residual;
+      wr = weight * residual;
+      is_inlier = inlier;
+      J[0] = n_m.x;
+      J[1] = n_m.y;
+      J[2] = n_m.z;
+      J[3] = cp.x;
+      J[4] = cp.y;
+      J[5] = cp.z;
+      wgt = weight;
+    }
+    /* words 0..15: the first 16 entries of the upper triangle of J^T W J (row-major: (0,0)..(0,5), (1,1)..(1,5),
+     * (2,2)..(2,5), (3,3)) */
+    {
+      long long h[16];
+      int k = 0;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-          float wJi = weight * J[i];
+      for (int i = 0; i < 6; ++i) {
+        const float wJi = wgt * J[i];
 #pragma unroll
-          for (int j = i; j < 6; ++j) acc[k++] += fix_bits(wJi * J[j], fx_scale, fx_magic);
+        for (int j = i; j < 6; ++j) {
+          if (k < 16) h[k] = (pair && is_inlier) ? fix_bits(wJi * J[j], fx_scale, fx_magic) : 0ll;
+          ++k;
         }
-        float wr = weight * residual;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) acc[21 + i] += fix_bits(wr * J[i], fx_scale, fx_magic);
-        acc[28] += fix_bits(wr2, fx_scale, fx_magic);
-      } else {
-        acc[30] += 1;
       }
-    } else {
-      acc[31] += 1;
+      totA += wave_reduce16(h, lane);
+    }
+    /* words 16..31: the last five entries of the triangle ((3,4) (3,5) (4,4) (4,5) (5,5)), J^T W r, F, F over the
+     * inliers, the three counters */
+    {
+      long long h[16];
+      const bool in = pair && is_inlier;
+      h[0] = in ? fix_bits((wgt * J[3]) * J[4], fx_scale, fx_magic) : 0ll;
+      h[1] = in ? fix_bits((wgt * J[3]) * J[5], fx_scale, fx_magic) : 0ll;
+      h[2] = in ? fix_bits((wgt * J[4]) * J[4], fx_scale, fx_magic) : 0ll;
+      h[3] = in ? fix_bits((wgt * J[4]) * J[5], fx_scale, fx_magic) : 0ll;
+      h[4] = in ? fix_bits((wgt * J[5]) * J[5], fx_scale, fx_magic) : 0ll;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) h[5 + i] = in ? fix_bits(wr * J[i], fx_scale, fx_magic) : 0ll;
+      h[11] = pair ? fix_bits(wr2, fx_scale, fx_magic) : 0ll; /* word 27 */
+      h[12] = in ? fix_bits(wr2, fx_scale, fx_magic) : 0ll;   /* word 28 */
+      h[13] = pair ? 1ll : 0ll;                               /* word 29: valid */
+      h[14] = (pair && !is_inlier) ? 1ll : 0ll;               /* word 30: outlier */
+      h[15] = (valid_px && !pair) ? 1ll : 0ll;                /* word 31: invalid */
+      totB += wave_reduce16(h, lane);
     }
   }
 
-  /* wave butterfly -> LDS -> block partial (plain stores: the next launch reads them) */
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  long long tot = wave_reduce32(acc, lane);
-  if ((lane & 1) == 0) s_wave[wave][word_of_lane(lane)] = tot;
+  /* wave totals -> LDS -> block sums -> accumulator record */
+  if ((lane & 3) == 0) {
+    s_wave[wave][word16_of_lane(lane)] = totA;
+    s_wave[wave][16 + word16_of_lane(lane)] = totB;
+  }
   __syncthreads();
   if (threadIdx.x < SUMA_ACC_WORDS) {
     long long s = 0;
