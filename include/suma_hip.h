@@ -165,7 +165,7 @@ int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, cons
 int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
                                       const float* d_probs, uint32_t n, int32_t fixed_iterations);
 /* ---- device-side scan ingest (KITTIReader::read hands over host vectors, KITTIReader.cpp:136-203 ->
- *      SurfelMapping::processScan(const rv::Laserscan&), SurfelMapping.cpp:175): two pinned staging slots, a copy
+ *      SurfelMapping::processScan(const rv::Laserscan&), SurfelMapping.cpp:175): three pinned staging slots, a copy
  *      stream and an ingest thread.  prefetch stages the scan (host copy into pinned memory + async H2D, both off
  *      the caller's thread) and returns at once; process_prefetched runs the oldest staged scan, its first kernel
  *      waiting on the upload's event.  Calling prefetch(scan k+1) before process_prefetched(scan k) overlaps the

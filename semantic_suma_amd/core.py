@@ -642,20 +642,24 @@ class SurfelMapping:
         """run an iterable of (points, labels, probs) with the upload of scan k+1 overlapping the kernels of scan k
         (what a reader thread feeding SurfelMapping::processScan does in the reference's visualizer loop)"""
         it = iter(scans)
-        nxt = next(it, None)
-        if nxt is None:
-            return 0
-        self.prefetchScan(*nxt[:3])
+        ahead = 0
         k = 0
-        while nxt is not None:
-            nxt = next(it, None)
-            if nxt is not None:
+        more = True
+        while True:
+            while more and ahead < 3:  # keep two scans staged beyond the one about to be processed
+                nxt = next(it, None)
+                if nxt is None:
+                    more = False
+                    break
                 self.prefetchScan(*nxt[:3])
+                ahead += 1
+            if ahead == 0:
+                return k
             self.processPrefetched(fixed_iterations)
+            ahead -= 1
             if on_scan is not None:
                 on_scan(k, self)
             k += 1
-        return k
 
     def getCurrentPose(self):
         T = np.zeros((4, 4), dtype=np.float64)

@@ -5,14 +5,15 @@
  * rv::Laserscan in pageable host memory and SurfelMapping::processScan (SurfelMapping.cpp:175-210, :323-331) assigns
  * it to GL buffers with a blocking glBufferData on the thread that owns the GL context.
  *
- * Here: two staging slots, each a pinned host block + a device block, a copy stream and one ingest thread.
+ * Here: three staging slots, each a pinned host block + a device block, a copy stream and one ingest thread.
  *   suma_pipeline_prefetch_scan       hands (points, labels, probs, n) to the ingest thread and returns at once;
  *                                     the thread copies the arrays into the slot's pinned block, enqueues the
  *                                     H2D copies on the copy stream and records the slot's event;
  *   suma_pipeline_process_prefetched  makes the compute stream wait on that event (device-side dependency, the
  *                                     host does not block on the copy) and runs the scan from the device block.
- * With prefetch(k+1) issued before process(k), the host copy and the PCIe transfer of scan k+1 overlap the
- * kernels of scan k.  A slot is refilled (scan k+2) only after the `consumed` event recorded on the compute stream
+ * With prefetch(k+1) (and k+2) issued before process(k), the host copy and the PCIe transfer of the next scans
+ * overlap the kernels of scan k: staging one scan (a ~3 MB host copy into pinned memory, ~250 us on one core, plus
+ * ~60 us of DMA) takes about as long as processing one, so it needs a head start of two scans to stay hidden.  A slot is refilled (scan k+2) only after the `consumed` event recorded on the compute stream
  * behind scan k has completed: the upload that read the pinned block and the preprocessing kernels that read the
  * device block are both behind it.
  */
@@ -23,6 +24,8 @@
 #include <thread>
 
 #include "suma_internal.h"
+
+#define INGEST_SLOTS 3u
 
 struct IngestSlot {
   /* request */
@@ -43,8 +46,8 @@ struct IngestSlot {
 struct Ingest {
   suma_pipeline* s;
   hipStream_t copy_stream;
-  IngestSlot slot[2];
-  uint32_t head, tail; /* next slot to process / next slot to fill (counts, slot = count & 1) */
+  IngestSlot slot[INGEST_SLOTS];
+  uint32_t head, tail; /* next slot to process / next slot to fill (counts, slot = count % INGEST_SLOTS) */
   std::mutex mu;
   std::condition_variable cv;
   std::thread worker;
@@ -82,9 +85,9 @@ static void ingest_main(Ingest* g) {
     IngestSlot* q;
     {
       std::unique_lock<std::mutex> lk(g->mu);
-      g->cv.wait(lk, [&] { return g->stop || (next != g->tail && g->slot[next & 1].state == 1); });
+      g->cv.wait(lk, [&] { return g->stop || (next != g->tail && g->slot[next % INGEST_SLOTS].state == 1); });
       if (g->stop) return;
-      q = &g->slot[next & 1];
+      q = &g->slot[next % INGEST_SLOTS];
     }
     hipError_t e = hipSuccess;
     if (q->consumed_valid) e = hipEventSynchronize(q->consumed); /* previous user of this slot has finished */
@@ -168,11 +171,11 @@ extern "C" int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* 
   int r = ingest_get(s, &g);
   if (r) return r;
   std::lock_guard<std::mutex> lk(g->mu);
-  if (g->tail - g->head >= 2) {
-    s->c->err = "suma_pipeline_prefetch_scan: both staging slots hold scans that have not been processed";
+  if (g->tail - g->head >= INGEST_SLOTS) {
+    s->c->err = "suma_pipeline_prefetch_scan: all staging slots hold scans that have not been processed";
     return SUMA_ERR_INVALID;
   }
-  IngestSlot* q = &g->slot[g->tail & 1];
+  IngestSlot* q = &g->slot[g->tail % INGEST_SLOTS];
   q->points = points;
   q->labels = labels;
   q->probs = probs;
@@ -194,7 +197,7 @@ extern "C" int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_
       c->err = "suma_pipeline_process_prefetched: no scan has been prefetched";
       return SUMA_ERR_INVALID;
     }
-    q = &g->slot[g->head & 1];
+    q = &g->slot[g->head % INGEST_SLOTS];
     g->cv.wait(lk, [&] { return q->state == 2 || q->state == -1; }); /* copies enqueued (not: completed) */
     if (q->state == -1) {
       c->err = std::string("scan staging failed: ") + hipGetErrorString(q->error);
@@ -227,7 +230,7 @@ extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_flo
     Ingest* g = s->ingest;
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->head != g->tail) {
-      const IngestSlot& q = g->slot[g->head & 1];
+      const IngestSlot& q = g->slot[g->head % INGEST_SLOTS];
       staged = (q.points == points && q.labels == labels && q.probs == probs && q.n == n);
       if (!staged) {
         s->c->err = "suma_pipeline_process_scan_async: a different scan is staged ahead of this one";

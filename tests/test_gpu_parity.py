@@ -711,8 +711,9 @@ def test_async_ingest_equals_resident_scans(hip):
         a.processPrefetched()
     a.prefetchScan(*scans_[0])
     a.prefetchScan(*scans_[1])
+    a.prefetchScan(*scans_[2])
     with pytest.raises(hip.SumaError):
-        a.prefetchScan(*scans_[2])  # both slots staged
+        a.prefetchScan(*scans_[3])  # all three slots staged
 
 
 _GATHER_SCRIPT = r"""
