@@ -81,3 +81,22 @@ def test_sequences_as_concurrent_pipelines():
     assert sorted(a) == [0, 1, 2]
     for s in a:
         assert a[s][0] == lengths[s] and np.array_equal(a[s][1], b[s][1]), f"sequence {s}"
+
+
+def test_bench_contract_with_two_ranks_on_one_device():
+    """bench.py's N > 1 path end to end -- torch.distributed.run, one process per rank, barrier + max-over-ranks timing,
+    the pose gather, rank 0's JSON line -- with two ranks sharing this box's one GPU (gloo; RCCL needs a GPU per rank)"""
+    import json
+    import subprocess
+    env = dict(os.environ, SUMA_BENCH_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
+           "--warmup", "2", "--backend", "gloo", "--cpu-scans", "0", "--no-kernel-events"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak"
+    assert d["value"] > 100 and abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6 / 1000.0)) < 1e-6 * d["value"]
+    assert d["roofline"]["kernel"] == "k6_icp_step" and "cpu_baseline" not in d
+    assert d["config"]["drift_m"] < 0.5
