@@ -2,7 +2,8 @@
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module; the
 product package never does.  The oracle is a CPU restatement of the reference's GLSL path
-(parity unpinned: the reference ships no golden vectors).
+(pinned to the reference's own shader sources compiled with g++: oracle/_ref, tests/test_ref_shaders.py; the
+reference ships no golden vectors of its own).
 """
 from __future__ import annotations
 

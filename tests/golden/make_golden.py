@@ -2,7 +2,8 @@
 """Generates tests/golden/*.npz from the CPU oracle (oracle/).
 
 The reference cannot be built or run (OpenGL + glow + Eigen + gtsam + Qt) and ships no
-golden vectors, so these fixtures do NOT pin the oracle to the reference ("parity unpinned"); they pin
+golden vectors, so these fixtures do NOT pin the oracle to the reference (that is the job of oracle/_ref +
+tests/test_ref_shaders.py, which compile the reference's own shaders); they pin
 the oracle -- and, on the GPU, the HIP path -- against regressions, on a fixed seeded input.
 Run from the repo root:  python tests/golden/make_golden.py
 """

@@ -1,5 +1,6 @@
 """Known-answer tests that pin the CPU oracle (oracle/) -- the reference ships no tests, golden vectors or
-fixtures ("parity unpinned"), so the oracle is pinned by closed-form answers derived from
+fixtures; besides the stage-by-stage comparison with the reference's own shaders compiled by g++
+(tests/test_ref_shaders.py), the oracle is pinned by closed-form answers derived from
 the reference's formulas, by invariants, and by an independent build with glibc transcendentals.
 """
 import numpy as np

@@ -56,15 +56,14 @@ def conf_threshold(p, t):
     return float(ct)
 
 
-@pytest.fixture(scope="module")
-def sequence(oracle_lib, scans):
+def run_sequence(oracle_lib, scans, n_scans, **overrides):
     """One oracle pipeline run, every stage checked against the compiled reference shaders on the way."""
-    p = params_with_size(W, H, max_surfels=1 << 19)
+    p = params_with_size(W, H, max_surfels=1 << 19, **overrides)
     pipe = oracle_lib.OraclePipeline(p)
     ref = pyref.Ref(p)
     log = {"scans": 0, "k9_integrated": 0, "k9_dropped": 0, "quads": 0, "extractions": 0, "origin_shifts": 0, "slerp_nan": 0}
     ora = pipe.ctx
-    for t in range(N_SCANS):
+    for t in range(n_scans):
         pts, lab, prob, _ = scans(t, W, True, H)
         before = ora.map_surfels()
         origin_before = ora.map_submap_origin()
@@ -153,6 +152,26 @@ def sequence(oracle_lib, scans):
         eq(comp[2], model.semantic, f"scan {t} K5 composed semantic map")
         log["scans"] += 1
     return {"pipe": pipe, "ref": ref, "params": p, "log": log, "oracle_lib": oracle_lib}
+
+
+@pytest.fixture(scope="module")
+def sequence(oracle_lib, scans):
+    return run_sequence(oracle_lib, scans, N_SCANS)
+
+
+@pytest.mark.parametrize("overrides", [
+    dict(weighting_scheme=1), dict(weighting_scheme=2, averaging_scheme=1), dict(confidence_mode=1),
+    dict(confidence_mode=2, sigma_distance=0.3), dict(confidence_mode=0), dict(use_stability=0),
+    dict(update_always=1), dict(unstable_age=1, confidence_threshold=0.3, p_stable=0.8, p_prior=0.4),
+    dict(map_max_distance=0.05, map_max_angle=10.0), dict(min_radius=0.05, max_radius=0.2, max_angle=60.0),
+    dict(compose_rendering=0), dict(label_offset=0, prob_offset=0), dict(submap_extent=3.0, submap_dimension=2),
+], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_every_stage_with_the_switches_default_xml_leaves_off(oracle_lib, scans, overrides):
+    """the branches of update_surfels.vert / init_radiusConf.vert / copy_surfels.vert that config/default.xml does not
+    take (weighting and averaging schemes, confidence models, stability off, update_always, tight gates, small
+    submaps), against the compiled reference shaders on a live 7-scan run"""
+    out = run_sequence(oracle_lib, scans, 7, **overrides)
+    assert out["log"]["scans"] == 7 and out["log"]["k9_integrated"] > 1000
 
 
 def test_every_stage_along_a_sequence(sequence):
