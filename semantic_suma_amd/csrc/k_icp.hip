@@ -30,6 +30,21 @@
  */
 #include "suma_internal.h"
 
+/* -DSUMA_GN_TIMING (tools/gn_timeline.py builds such a library next to the product one): every block stamps
+ * wall_clock64 (100 MHz) at the stations of a launch into g_gn_timing[blockIdx.x][station] */
+#ifdef SUMA_GN_TIMING
+__device__ unsigned long long g_gn_timing[256][8];
+#define GN_STAMP(k)                                                                            \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.x < 256) g_gn_timing[blockIdx.x][k] = wall_clock64(); \
+  } while (0)
+extern "C" int suma_debug_gn_timing(unsigned long long* host /* 256 x 8 */) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_gn_timing), sizeof(g_gn_timing));
+}
+#else
+#define GN_STAMP(k) ((void)0)
+#endif
+
 #define ICP_THREADS 512 /* 8 waves per block, one block per CU: 131072 lanes = one 64x2048 image in flight */
 #define MAGIC_D 6755399441055744.0          /* 1.5 * 2^52 */
 #define MAGIC_BITS 0x4338000000000000ll     /* its bit pattern */
@@ -369,6 +384,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     for (uint32_t h = blockIdx.y; h < g.zero_hyp; h += gridDim.y)
       g.pzero[(size_t)h * ICP_RECORDS * SUMA_ACC_WORDS + threadIdx.x] = 0;
 
+  GN_STAMP(0); /* block started */
   /* Everything this block needs from memory before it can compute is requested up front and TOGETHER -- the
    * previous launch's accumulator records (wave 0: four words per lane), the pose columns of lanes 0..15, this
    * lane's data-frame texels -- so that the prologue pays one cold round trip, not a chain of them: none of these
@@ -415,6 +431,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
        *      order), removes the fixed-point bias and converts: word w of the totals and its value in double land
        *      in LDS for the solve ---- */
       long long sum = (rec[0] + rec[1]) + (rec[2] + rec[3]);
+      GN_STAMP(1); /* state words + records have arrived */
       sum += shfl_xor_ll(sum, 32);
       const long long n_valid = readlane_ll(sum, 29), n_outlier = readlane_ll(sum, 30), n_inlier = n_valid - n_outlier;
       const int w = threadIdx.x & 31;
@@ -476,7 +493,9 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       double last_error = gin->last_error;
       if (!g.eval_only) {
         double dx[6];
+        GN_STAMP(2); /* folded, converted, about to solve */
         solve6_wave(s_val, lane, dx);
+        GN_STAMP(3); /* solved */
         int result = 1;
         double linf = 0.0, maxc = s_val[21];
 #pragma unroll
@@ -491,6 +510,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         if (err < last_error && (de < 0 ? -de : de) < g.epsilon) result = 0;  /* :66 */
         double E[16];
         se3_exp(dx, E);
+        GN_STAMP(7); /* exp(delta) formed */
         if (lane == 0) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) s_E[i] = E[i];
@@ -533,6 +553,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         if (blockIdx.x == 0) gout->Tk[lane] = t;
       }
     }
+    GN_STAMP(4); /* wave 0: exp + pose product + state stores issued */
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 16; ++i) Tk[i] = s_pose[i];
@@ -743,6 +764,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     }
   }
 
+  GN_STAMP(5); /* pixel phase + wave reductions done (thread 0's wave) */
   /* wave totals -> LDS -> block sums -> accumulator record */
   if ((lane & 3) == 0) {
     s_wave[wave][word16_of_lane(lane)] = totA;
@@ -799,6 +821,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       }
     }
   }
+  GN_STAMP(6); /* adds issued */
   if (prefetch_sink == 1.2345678e-30f && writer) gout->pad[0] = 1; /* keeps the prefetch loads alive */
   if (writer) gout->pending = 1;
 }
