@@ -98,7 +98,29 @@ typedef struct suma_params {
   /* capacity (in surfels) of the HBM arena that holds the parked submap tiles; the reference keeps
    * them in host RAM (SurfelMap.h:186).  0 = 16 * max_surfels. */
   uint32_t cache_surfels;
+  /* optional vertex-map filters of Preprocessing (Preprocessing.cpp:76-90,150-236); config/default.xml leaves
+   * `avg_vertexmap` / `filter_vertexmap` out (= off) and holds no `bilateral_sigma_space` at all.
+   *   avg_vertexmap          K1 without depth test, additive blending (sums of (x,y,z,1) and of the label texel,
+   *                          in point order), then K1b avg_vertexmap.frag divides the vertex sum by its count
+   *   filter_vertexmap       K1c bilateral_filter.frag (13x13 range filter); its output replaces the vertex map
+   *                          only when use_filtered_vertexmap is set (Preprocessing.cpp:234), as in the reference
+   *   filter_sampling        how the two filter shaders see their input texture.  They sample a rectangle
+   *                          texture at INTEGER coordinates with no sampler object bound (Preprocessing.cpp:198,
+   *                          217), i.e. with the texture's own state, which un-vendored glow sets.
+   *                          SUMA_FILTER_SAMPLING_GL_INITIAL = the GL initial state of a rectangle texture
+   *                          (LINEAR, CLAMP_TO_EDGE: GL 3.3 core 3.8.15) -- an integer coordinate is a texel
+   *                          CORNER, the fetch averages the four texels around it; SUMA_FILTER_SAMPLING_NEAREST
+   *                          = texel (x, y) itself. */
+  int32_t avg_vertexmap;
+  int32_t filter_vertexmap;
+  int32_t use_filtered_vertexmap;
+  float bilateral_sigma_space; /* no default in default.xml: must be > 0 when filter_vertexmap is set */
+  float bilateral_sigma_range; /* default.xml:79 */
+  int32_t filter_sampling;
 } suma_params;
+
+#define SUMA_FILTER_SAMPLING_GL_INITIAL 0
+#define SUMA_FILTER_SAMPLING_NEAREST 1
 
 /* Unpacked row 7 of the reference's 2x8 blend target (Frame2Model.cpp:222-227) */
 typedef struct suma_icp_stats {
@@ -171,6 +193,12 @@ static inline void suma_params_default(suma_params* p) {
   p->label_offset = 4;
   p->prob_offset = 5;
   p->cache_surfels = 0;
+  p->avg_vertexmap = 0;
+  p->filter_vertexmap = 0;
+  p->use_filtered_vertexmap = 0;
+  p->bilateral_sigma_space = 0.0f;
+  p->bilateral_sigma_range = 2.5f;
+  p->filter_sampling = SUMA_FILTER_SAMPLING_GL_INITIAL;
 }
 
 #ifdef __cplusplus

@@ -510,15 +510,21 @@ inline mat4 inverse(const mat4& M) {
 #endif
 }
 
-/* ---- samplers: rectangle textures (unnormalised coordinates), CLAMP_TO_BORDER with border colour 0 ---- */
-enum { GLSL_NEAREST = 0, GLSL_LINEAR = 1 };
+/* ---- samplers: rectangle textures (unnormalised coordinates); CLAMP_TO_BORDER with border colour 0 (the sampler
+ * objects the reference binds) or CLAMP_TO_EDGE (the GL initial state of a rectangle texture) ---- */
+enum { GLSL_NEAREST = 0, GLSL_LINEAR = 1, GLSL_CLAMP_TO_EDGE = 2 /* flag, or-ed into the filter argument */ };
 struct sampler2DRect {
   const float* data;
   int w, h, ch; /* ch = 1 (R32F: (r,0,0,1)) or 4 (RGBA32F) */
   int filter;
-  sampler2DRect() : data(nullptr), w(0), h(0), ch(4), filter(GLSL_NEAREST) {}
+  int edge;
+  sampler2DRect() : data(nullptr), w(0), h(0), ch(4), filter(GLSL_NEAREST), edge(0) {}
 };
 inline vec4 glsl_texel(const sampler2DRect& s, int i, int j) {
+  if (s.edge && s.data) {
+    i = i < 0 ? 0 : (i >= s.w ? s.w - 1 : i);
+    j = j < 0 ? 0 : (j >= s.h ? s.h - 1 : j);
+  }
   if (!s.data || i < 0 || j < 0 || i >= s.w || j >= s.h) return vec4(0.f, 0.f, 0.f, 0.f);
   const float* t = s.data + ((size_t)j * (size_t)s.w + (size_t)i) * (size_t)s.ch;
   return s.ch == 4 ? vec4(t[0], t[1], t[2], t[3]) : vec4(t[0], 0.f, 0.f, 1.f);
@@ -538,7 +544,20 @@ inline vec4 texture(const sampler2DRect& s, const vec2& c) {
   float a = u - fu, b = v - fv;
   int i0 = (int)fu, j0 = (int)fv;
   vec4 t00 = glsl_texel(s, i0, j0), t10 = glsl_texel(s, i0 + 1, j0), t01 = glsl_texel(s, i0, j0 + 1), t11 = glsl_texel(s, i0 + 1, j0 + 1);
-  return t00 * ((1.0f - a) * (1.0f - b)) + t10 * (a * (1.0f - b)) + t01 * ((1.0f - a) * b) + t11 * (a * b);
+  /* a tap whose weight is exactly 0 contributes nothing, whatever it holds: at a texel centre (a = b = 0) the
+   * fetch is the texel itself even beside a NaN / inf texel (GL 3.3 core 2.1.1 leaves arithmetic on NaN / inf
+   * undefined; 0 * NaN = NaN would poison every texel left of / below a NaN one).  The remaining products are added
+   * in the order of the spec's formula. */
+  const float w[4] = {(1.0f - a) * (1.0f - b), a * (1.0f - b), (1.0f - a) * b, a * b};
+  const vec4* t[4] = {&t00, &t10, &t01, &t11};
+  vec4 r(0.f, 0.f, 0.f, 0.f);
+  bool any = false;
+  for (int k = 0; k < 4; ++k) {
+    if (w[k] == 0.0f) continue;
+    r = any ? r + *t[k] * w[k] : *t[k] * w[k];
+    any = true;
+  }
+  return r;
 }
 struct samplerBuffer {
   const float* data; /* RGBA32F texels */

@@ -22,7 +22,7 @@ from semantic_suma_amd.types import SURFEL_DTYPE, SumaParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
-NEAREST, LINEAR = 0, 1
+NEAREST, LINEAR, CLAMP_TO_EDGE = 0, 1, 2
 
 
 def build(force=False):
@@ -51,6 +51,7 @@ def lib(variant=""):
     L.ref_bind_texture.argtypes = [C.c_char_p, C.c_char_p, vp, i32, i32, i32, i32]
     L.ref_bind_buffer.argtypes = [C.c_char_p, C.c_char_p, vp, i32]
     L.ref_draw_vertexmap.argtypes = [vp, vp, vp, u32, i32, i32, vp, vp]
+    L.ref_draw_vertexmap_blend.argtypes = [vp, vp, vp, u32, i32, i32, vp, vp]
     for n in ("ref_pass_normalmap",):
         getattr(L, n).argtypes = [i32, i32, vp, vp]
     for n in ("ref_pass_floodfill", "ref_pass_avg_vertexmap", "ref_pass_bilateral", "ref_draw_radius_conf"):
@@ -166,7 +167,8 @@ class Ref:
             self._u(prog, "width", self.Wm if model else self.W, required=False)
             self._u(prog, "height", self.Hm if model else self.H, required=False)
 
-    # -- K1-K3  Preprocessing::process (Preprocessing.cpp:120-339), filters off (default.xml:80)
+    # -- K1-K3  Preprocessing::process (Preprocessing.cpp:120-339); the filter passes (:150,160-166,191-236) run with
+    #    the texture's own sampling state, which `filter_sampling` names (suma_types.h)
     def preprocess(self, points, labels, probs, timestamp):
         p = self.p
         W, H = self.W, self.H
@@ -185,7 +187,25 @@ class Ref:
         self._u("gen_vertexmap", "isfirst", 1 if timestamp < 10 else 0, "i")
         vmap = np.zeros((H, W, 4), dtype=np.float32)
         smap = np.zeros((H, W, 4), dtype=np.float32)
-        self.L.ref_draw_vertexmap(_p(points), _p(lab), _p(prb), n, W, H, _p(vmap), _p(smap))
+        own = NEAREST if int(p.filter_sampling) == 1 else (LINEAR | CLAMP_TO_EDGE)
+        if p.avg_vertexmap:
+            temp = np.zeros((H, W, 4), dtype=np.float32)
+            self.L.ref_draw_vertexmap_blend(_p(points), _p(lab), _p(prb), n, W, H, _p(temp), _p(smap))
+            self._tex("avg_vertexmap", "in_vertexmap", temp, own)
+            self.L.ref_pass_avg_vertexmap(W, H, _p(vmap))
+        else:
+            self.L.ref_draw_vertexmap(_p(points), _p(lab), _p(prb), n, W, H, _p(vmap), _p(smap))
+        if p.filter_vertexmap:
+            prog = "bilateral_filter"
+            self._u(prog, "width", W)
+            self._u(prog, "height", H)
+            self._u(prog, "sigma_space", p.bilateral_sigma_space)
+            self._u(prog, "sigma_range", p.bilateral_sigma_range)
+            self._tex(prog, "in_vertexmap", vmap, own)
+            temp = np.zeros((H, W, 4), dtype=np.float32)
+            self.L.ref_pass_bilateral(W, H, _p(temp))
+            if p.use_filtered_vertexmap:
+                vmap = temp  # Preprocessing.cpp:234
         # pass 2 (Preprocessing.cpp:238-279): sampler NEAREST + CLAMP_TO_BORDER (:68-70)
         self._tex("gen_normalmap", "vertex_map", vmap, NEAREST)
         self._tex("gen_normalmap", "semantic_map", smap, NEAREST)

@@ -76,7 +76,8 @@ int ref_bind_texture(const char* prog, const char* name, const float* data, int 
     s.w = w;
     s.h = h;
     s.ch = ch;
-    s.filter = filter;
+    s.filter = filter & 1;
+    s.edge = (filter & GLSL_CLAMP_TO_EDGE) != 0;
     ++hits;
   }
   return hits;
@@ -158,6 +159,39 @@ void ref_draw_vertexmap(const float* pts4, const float* label, const float* prob
     store4(smap4, pix, FS::semantic_map);
   }
   free(depth);
+}
+
+/* K1 with avgVertexmap_ (Preprocessing.cpp:150,160-166): the same draw with the depth test disabled and
+ * glBlendFunc(GL_ONE, GL_ONE) on both attachments; fragments blend in primitive order. */
+void ref_draw_vertexmap_blend(const float* pts4, const float* label, const float* prob, uint32_t n, int W, int H,
+                              float* vmap4, float* smap4) {
+  namespace VS = s_gen_vertexmap_vert;
+  namespace FS = s_gen_vertexmap_frag;
+  const size_t P = (size_t)W * H;
+  memset(vmap4, 0, P * 16);
+  memset(smap4, 0, P * 16);
+  for (uint32_t i = 0; i < n; ++i) {
+    VS::position = vec4(pts4[4 * i], pts4[4 * i + 1], pts4[4 * i + 2], pts4[4 * i + 3]);
+    VS::label = label[i];
+    VS::prob = prob[i];
+    VS::gl_VertexID = (int)i;
+    VS::shader_main();
+    raster_point rp;
+    if (!rasterize_point(VS::gl_Position, W, H, &rp)) continue;
+    size_t pix = (size_t)rp.py * W + rp.px;
+    FS::vertex_coord = VS::vertex_coord;
+    FS::vert_label = VS::vert_label;
+    FS::vert_label_prob = VS::vert_label_prob;
+    FS::shader_main();
+    const vec4 src[2] = {FS::color, FS::semantic_map};
+    float* dst[2] = {vmap4 + 4 * pix, smap4 + 4 * pix};
+    for (int a = 0; a < 2; ++a) { /* C = Cs * 1 + Cd * 1 in the fp32 colour buffer */
+      dst[a][0] = src[a].x * 1.0f + dst[a][0] * 1.0f;
+      dst[a][1] = src[a].y * 1.0f + dst[a][1] * 1.0f;
+      dst[a][2] = src[a].z * 1.0f + dst[a][2] * 1.0f;
+      dst[a][3] = src[a].w * 1.0f + dst[a][3] * 1.0f;
+    }
+  }
 }
 
 /* full-screen passes: empty.vert + quad.geom (texCoords in [0,1]^2, interpolated: (x + 1/2) / W at a pixel

@@ -12,6 +12,8 @@
  *
  * Layout: every map is a row-major W x H array of float4 (row 0 = lowest beam); one thread per
  * texel, 16 B per lane.  K2 + K3 run as ONE kernel over LDS-staged tiles (k23_normals_labels).
+ * The optional filters between K1 and K2 (avg_vertexmap, filter_vertexmap: off in config/default.xml) live in
+ * k_filters.hip.
  */
 #include "suma_internal.h"
 
@@ -187,12 +189,19 @@ hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_la
   hipStream_t st = c->ls;
   /* on the scan pipeline's side stream K1 runs while K7 / K10 of the previous scan may still use zbuf_data */
   unsigned long long* zbuf = (st != c->stream && c->zbuf_k1) ? c->zbuf_k1 : c->zbuf_data;
-  {
+  if (c->p.avg_vertexmap) { /* Preprocessing.cpp:150,160-166,191-213 (k_filters.hip) */
+    hipError_t e = launch_k1_average(c, d_pts, d_labels, d_probs, n, timestamp, out->map[SUMA_MAP_VERTEX], c->eroded);
+    if (e != hipSuccess) return e;
+  } else {
     ProfScope ps(c, "k1_vertexmap", 24.0 * n + 32.0 * P);
     if (n > 0) k1_scatter<<<(n + 255) / 256, 256, 0, st>>>(d_pts, n, c->pd, zbuf);
     k1_resolve<<<(P + 255) / 256, 256, 0, st>>>(zbuf, d_pts, d_labels, d_probs, n, c->p.label_offset,
                                                  c->p.prob_offset, timestamp < 10 ? 1 : 0, out->map[SUMA_MAP_VERTEX],
                                                  c->eroded /* raw labels: scratch */, P);
+  }
+  if (c->p.filter_vertexmap && c->p.use_filtered_vertexmap) { /* :215-236; without use_filtered the result is dropped */
+    hipError_t e = launch_k1c_bilateral(c, out->map[SUMA_MAP_VERTEX]);
+    if (e != hipSuccess) return e;
   }
   {
     ProfScope ps(c, "k2k3_normals_labels", 64.0 * P);

@@ -212,6 +212,18 @@ static int map_reset_impl(suma_ctx* c) {
   return SUMA_OK;
 }
 
+/* the optional vertex-map filters (suma_types.h): what the reference would throw on, and what k_filters.hip covers */
+static const char* filter_params_error(const suma_params* p) {
+  if (p->filter_sampling != SUMA_FILTER_SAMPLING_GL_INITIAL && p->filter_sampling != SUMA_FILTER_SAMPLING_NEAREST)
+    return "filter_sampling: unknown value";
+  if (p->filter_vertexmap && !(p->bilateral_sigma_space > 0.0f && p->bilateral_sigma_range > 0.0f))
+    return "filter_vertexmap needs bilateral_sigma_space and bilateral_sigma_range > 0 (config/default.xml holds no "
+           "bilateral_sigma_space; Preprocessing.cpp:86 would throw on the missing key)";
+  if ((p->filter_vertexmap || p->avg_vertexmap) && (p->data_width > 8192 || p->data_height > 8192))
+    return "avg_vertexmap / filter_vertexmap: images above 8192 texels per side are not covered (k_filters.hip)";
+  return nullptr;
+}
+
 extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_ctx** out) {
   if (!params || !out) {
     g_create_error = "suma_ctx_create: null argument";
@@ -234,6 +246,10 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     g_create_error = "suma_ctx_create: zero image size or capacity";
     return SUMA_ERR_INVALID;
   }
+  if (const char* fe = filter_params_error(params)) {
+    g_create_error = std::string("suma_ctx_create: ") + fe;
+    return SUMA_ERR_INVALID;
+  }
   suma_ctx* c = new (std::nothrow) suma_ctx();
   if (!c) {
     g_create_error = "out of host memory";
@@ -252,6 +268,11 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   c->side_stream = nullptr;
   c->sync_flags = nullptr;
   c->zbuf_k1 = nullptr;
+  c->filt_temp = nullptr;
+  c->filt_sort = nullptr;
+  c->filt_sort_tmp = nullptr;
+  c->filt_sort_tmp_bytes = 0;
+  c->filt_cap = 0;
   derive(c);
   c->P = (size_t)params->data_width * params->data_height;
   c->Pm = (size_t)params->model_width * params->model_height;
@@ -359,7 +380,8 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
   void* dev[] = {c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
-                 c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs, c->sync_flags, c->zbuf_k1};
+                 c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs, c->sync_flags, c->zbuf_k1,
+                 c->filt_temp, c->filt_sort, c->filt_sort_tmp};
   for (void* p : dev)
     if (p) hipFree(p);
   if (c->h_ds) hipHostFree(c->h_ds);
@@ -376,6 +398,10 @@ extern "C" int suma_set_params(suma_ctx* c, const suma_params* p) {
   if (p->data_width != c->p.data_width || p->data_height != c->p.data_height || p->model_width != c->p.model_width ||
       p->model_height != c->p.model_height || p->max_surfels != c->p.max_surfels || p->max_poses != c->p.max_poses)
     return fail(c, SUMA_ERR_INVALID, "suma_set_params: image sizes and capacities are fixed at creation");
+  if (const char* fe = filter_params_error(p)) {
+    c->err = std::string("suma_set_params: ") + fe;
+    return SUMA_ERR_INVALID;
+  }
   uint32_t cache = c->p.cache_surfels;
   c->p = *p;
   c->p.cache_surfels = cache;

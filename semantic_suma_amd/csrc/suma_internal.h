@@ -110,6 +110,12 @@ struct suma_ctx {
   unsigned long long* zbuf_data; /* P keys: K7 (and K1 outside the scan pipeline's side stream) */
   unsigned long long* zbuf_k1;   /* P keys: K1 of the scan pipeline -- preprocessing of scan t+1 overlaps K7 / K10 of scan t */
   float4* eroded;                /* P: raw labels of K1 (scratch between k1_resolve and the fused K2/K3) */
+  /* optional vertex-map filters (k_filters.hip), allocated on first use */
+  float4* filt_temp;             /* P: the reference's temp_vertices_ */
+  unsigned long long* filt_sort; /* 2 x filt_cap keys (pixel << 32 | point index), unsorted / sorted */
+  void* filt_sort_tmp;
+  size_t filt_sort_tmp_bytes;
+  uint32_t filt_cap;
   float4* scan_points;           /* staging for host scans */
   float *scan_labels, *scan_probs;
   uint32_t scan_cap;
@@ -257,6 +263,9 @@ struct ProfScope {
 hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_labels, const float* d_probs, uint32_t n,
                              uint32_t timestamp, suma_frame* out);
 /* k_icp.hip */
+hipError_t launch_k1_average(suma_ctx* c, const float4* d_pts, const float* d_labels, const float* d_probs, uint32_t n,
+                             uint32_t timestamp, float4* vertex, float4* raw_semantic);
+hipError_t launch_k1c_bilateral(suma_ctx* c, float4* vertex);
 hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0);
 hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
                                 int eval_only, int with_history, int pixel);

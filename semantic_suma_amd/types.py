@@ -11,6 +11,7 @@ WEIGHT_NONE, WEIGHT_HUBER, WEIGHT_TUKEY, WEIGHT_STABILITY = 0, 1, 2, 3
 MAP_VERTEX, MAP_NORMAL, MAP_SEMANTIC = 0, 1, 2
 FRAME_OLD, FRAME_NEW, FRAME_COMPOSED = 0, 1, 2
 ACC_WORDS = 32
+FILTER_SAMPLING_GL_INITIAL, FILTER_SAMPLING_NEAREST = 0, 1
 ACC_SCALE = 268435456.0
 
 # numpy view of the 64-byte surfel record (reference src/core/Surfel.h:5-15)
@@ -44,6 +45,8 @@ class SumaParams(C.Structure):
         ("submap_dimension", i32), ("submap_extent", f32), ("partial_extraction", i32),
         ("max_surfels", u32), ("max_poses", u32),
         ("label_offset", u32), ("prob_offset", u32), ("cache_surfels", u32),
+        ("avg_vertexmap", i32), ("filter_vertexmap", i32), ("use_filtered_vertexmap", i32),
+        ("bilateral_sigma_space", f32), ("bilateral_sigma_range", f32), ("filter_sampling", i32),
     ]
 
 
@@ -71,6 +74,8 @@ def default_params(**overrides) -> SumaParams:
         weighting_scheme=0, averaging_scheme=0, update_always=0,
         submap_dimension=4, submap_extent=10.0, partial_extraction=1,
         max_surfels=2048 * 2048, max_poses=10000, label_offset=4, prob_offset=5, cache_surfels=0,
+        avg_vertexmap=0, filter_vertexmap=0, use_filtered_vertexmap=0, bilateral_sigma_space=0.0,
+        bilateral_sigma_range=2.5, filter_sampling=FILTER_SAMPLING_GL_INITIAL,
     )
     for k, v in overrides.items():
         if not hasattr(p, k):

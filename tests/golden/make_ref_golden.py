@@ -11,6 +11,9 @@ reference's host code does).  No oracle code is involved in producing these vect
                     (update_surfels.vert:113-124; the one documented behavioural deviation)
   k6_acc            Frame2Model_jacobians at pose k6_T, data = frame1, model = frame0, one entry per invocation, every
                     emitted term summed in 2^-28 fixed point
+and tests/golden/ref_filters_180x16.npz: Preprocessing::process with the optional vertex-map filters
+(Preprocessing.cpp:150-236: blended K1 + avg_vertexmap.frag, bilateral_filter.frag) on a DENSE scan (about six points
+per texel, so the blended sums have several terms), one case per FILTER_CASES entry: vertex, normal, semantic map.
 The GPU suite compares the HIP path with these vectors directly (tests/test_ref_golden.py); /root/reference is only
 needed here, at generation time.  Run from the repo root:  python tests/golden/make_ref_golden.py
 """
@@ -28,6 +31,32 @@ from semantic_suma_amd.types import SURFEL_DTYPE, params_with_size  # noqa: E402
 from test_ref_shaders import unpack_fix  # noqa: E402
 
 W, H = 180, 16
+
+
+FILTER_CASES = {
+    "avg": dict(avg_vertexmap=1),
+    "avg_nearest": dict(avg_vertexmap=1, filter_sampling=1),
+    "bilateral": dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5, bilateral_sigma_range=2.5),
+    "bilateral_nearest": dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5,
+                              bilateral_sigma_range=2.5, filter_sampling=1),
+    "avg_bilateral_nearest": dict(avg_vertexmap=1, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=2.0,
+                                  bilateral_sigma_range=0.5, filter_sampling=1),
+}
+
+
+def filters():
+    pts, lab, prob, _ = synth.generate_scan(3, n_azimuth=3 * W, height=2 * H)
+    out = {"W": W, "H": H, "pts": pts, "lab": lab, "prob": prob}
+    for name, ov in FILTER_CASES.items():
+        p = params_with_size(W, H, max_surfels=1 << 16, max_poses=64, **ov)
+        ref = pyref.Ref(p)
+        for t in (0, 12):  # isfirst on / off (Preprocessing.cpp:176-179)
+            v, n, s = ref.preprocess(pts, lab, prob, t)
+            out[f"{name}_t{t}_vertex"], out[f"{name}_t{t}_normal"], out[f"{name}_t{t}_semantic"] = v, n, s
+    path = os.path.join(ROOT, "tests", "golden", "ref_filters_180x16.npz")
+    np.savez_compressed(path, **out)
+    v = out["avg_t12_vertex"]
+    print(f"{path}: {os.path.getsize(path) / 1024:.0f} KB; {pts.shape[0]} points, {int((v[..., 3] > 0.5).sum())} valid texels")
 
 
 def main():
@@ -73,3 +102,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+    filters()

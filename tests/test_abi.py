@@ -50,10 +50,10 @@ def test_ctypes_layouts_match_c(built, tmp_path):
     from semantic_suma_amd.core import IcpObjective, KernelTime, LoopResult
     from semantic_suma_amd.types import SURFEL_DTYPE, IcpStats, SumaParams
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "suma_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "suma_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(suma_params),sizeof(suma_icp_stats),sizeof(suma_surfel),sizeof(suma_kernel_time),"
                    "offsetof(suma_params,max_surfels),offsetof(suma_params,cache_surfels),sizeof(suma_icp_objective),"
-                   "sizeof(suma_loop_result));return 0;}\n")
+                   "sizeof(suma_loop_result),offsetof(suma_params,filter_sampling));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
@@ -61,6 +61,7 @@ def test_ctypes_layouts_match_c(built, tmp_path):
     assert sizes[2] == SURFEL_DTYPE.itemsize == 64 and sizes[3] == C.sizeof(KernelTime)
     assert sizes[4] == SumaParams.max_surfels.offset and sizes[5] == SumaParams.cache_surfels.offset
     assert sizes[6] == C.sizeof(IcpObjective) and sizes[7] == C.sizeof(LoopResult)
+    assert sizes[8] == SumaParams.filter_sampling.offset == C.sizeof(SumaParams) - 4
 
 
 def test_no_cpu_fallback(built):

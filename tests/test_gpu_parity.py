@@ -7,6 +7,8 @@ and kernels evaluate the same IEEE binary32 operation sequence (include/suma_det
 contraction) and the J^T J sums are exact fixed point, every float output is in fact compared
 BIT FOR BIT here; the tolerances appear only where stated.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -14,6 +16,7 @@ from conftest import assert_bit_equal, get_scan
 from semantic_suma_amd.types import params_with_size
 
 pytestmark = pytest.mark.gpu
+THREADS = max(1, min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="module")
@@ -48,6 +51,78 @@ def test_preprocess_k1_k3(hip, oracle_lib, width, semantics):
         frames_equal(hf, of, f"preprocess w={width} t={timestamp}")
         v = hf.download(0)
         assert 0.5 < float((v[..., 3] > 0).mean()) <= 1.0  # the synthetic scan fills most of the image
+
+
+FILTER_VARIANTS = [
+    dict(avg_vertexmap=1),
+    dict(avg_vertexmap=1, filter_sampling=1),
+    dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5, bilateral_sigma_range=2.5),
+    dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5, bilateral_sigma_range=2.5, filter_sampling=1),
+    dict(avg_vertexmap=1, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=2.0, bilateral_sigma_range=0.5),
+    dict(filter_vertexmap=1, use_filtered_vertexmap=0, bilateral_sigma_space=4.5),  # computed and dropped (Preprocessing.cpp:234)
+]
+
+
+@pytest.mark.parametrize("overrides", FILTER_VARIANTS, ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
+def test_preprocess_vertexmap_filters(hip, oracle_lib, overrides):
+    """Preprocessing.cpp:150-236: blended K1 + avg_vertexmap.frag, bilateral_filter.frag, both texture states; a dense
+    cloud (three scans stacked: ~3 points per texel, in three different orders) so that the ordered sums have terms"""
+    from semantic_suma_amd import synth
+    W, H = 2048, 64
+    p = params_with_size(W, H, **overrides)
+    ctx, ora = hip.Context(p), oracle_lib.Oracle(p, threads=THREADS)
+    a = synth.generate_scan(0, n_azimuth=W)
+    b = synth.generate_scan(0, n_azimuth=W, seed=99)
+    c = synth.generate_scan(0, n_azimuth=W, seed=7)
+    pts = np.concatenate([a[0], b[0][::-1], c[0]]).astype(np.float32)
+    lab = np.concatenate([a[1], b[1][::-1], c[1]]).astype(np.float32)
+    prob = np.concatenate([a[2], b[2][::-1], c[2]]).astype(np.float32)
+    for timestamp in (0, 12):
+        hf = hip.Frame(ctx, W, H)
+        hip.Preprocessing(ctx).process(pts, hf, lab, prob, timestamp)
+        of = ora.preprocess(pts, lab, prob, timestamp, ora.frame())
+        frames_equal(hf, of, f"filters {overrides} t={timestamp}")
+        assert float((hf.download(0)[..., 3] > 0.5).mean()) > 0.5
+    if overrides.get("avg_vertexmap"):
+        # pathological: every point in one texel (one run of n terms), plus clipped and NaN points
+        one = np.tile(np.array([[10.0, 0.0, 0.0, 1.0]], np.float32), (5000, 1))
+        one[:, 2] = np.linspace(-0.001, 0.001, 5000, dtype=np.float32)
+        one = np.concatenate([one, np.array([[0, 0, 0, 1], [np.nan, 1, 1, 1], [500, 0, 0, 1]], np.float32)])
+        hf = hip.Frame(ctx, W, H)
+        hip.Preprocessing(ctx).process(one, hf, None, None, 12)
+        of = ora.preprocess(one, None, None, 12, ora.frame())
+        frames_equal(hf, of, "all points in one texel")
+        empty = np.zeros((0, 4), np.float32)
+        hip.Preprocessing(ctx).process(empty, hf, None, None, 12)
+        of = ora.preprocess(empty, None, None, 12, ora.frame())
+        frames_equal(hf, of, "empty scan, filters on")
+
+
+def test_pipeline_with_vertexmap_filters(hip, oracle_lib):
+    W = 900
+    for overrides in (dict(avg_vertexmap=1, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=3.0,
+                           bilateral_sigma_range=1.0, filter_sampling=1),
+                      dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5)):
+        p = params_with_size(W, **overrides)
+        hp, op = hip.SurfelMapping(p), oracle_lib.OraclePipeline(p, threads=THREADS)
+        for k in range(5):
+            pts, lab, prob, _ = get_scan(k, W, True)
+            hp.processScan(pts, lab, prob, fixed_iterations=6)
+            op.process_scan(pts, lab, prob, fixed_iterations=6)
+            assert np.array_equal(hp.getCurrentPose(), op.pose()), f"{overrides} scan {k}: pose"
+            assert hp.lastStats().as_dict() == op.last_stats().as_dict()
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"{overrides}: map"
+        assert hp.map.size() > 20000
+
+
+def test_vertexmap_filter_parameter_errors(hip):
+    with pytest.raises(hip.SumaError, match="bilateral_sigma_space"):
+        hip.Context(params_with_size(900, filter_vertexmap=1))  # default.xml holds no bilateral_sigma_space
+    with pytest.raises(hip.SumaError, match="filter_sampling"):
+        hip.Context(params_with_size(900, filter_sampling=7))
+    ctx = hip.Context(params_with_size(900))
+    with pytest.raises(hip.SumaError, match="bilateral_sigma_space"):
+        ctx.set_params(params_with_size(900, filter_vertexmap=1))
 
 
 def test_preprocess_edge_cases(hip, oracle_lib):

@@ -194,3 +194,57 @@ def test_native_build_is_bit_identical(oracle_lib, scans):
         assert np.array_equal(a.pose(), b.pose()), f"scan {k}"
     assert a.ctx.map_surfels().tobytes() == b.ctx.map_surfels().tobytes()
     assert a.last_stats().as_dict() == b.last_stats().as_dict()
+
+
+def test_vertexmap_filters_known_answers(oracle_lib):
+    """Preprocessing.cpp:150-236 on hand-made inputs: the blended K1 sums a texel's points in index order (fp32, not
+    associative), avg_vertexmap.frag divides by the count, the bilateral filter on a constant-range patch;
+    and the texel a filter fragment addresses, int(((x + 1/2) / W) * W), is x for every image width up to 8192."""
+    for Wd in range(1, 8193):
+        px = np.arange(Wd, dtype=np.float32)
+        got = (((px + np.float32(0.5)) / np.float32(Wd)) * np.float32(Wd)).astype(np.int32)
+        assert np.array_equal(got, np.arange(Wd)), Wd
+    W, H = 64, 16
+    # three points in one texel whose x sum depends on the order: (1e8 + 1) - 1e8 = 0 in fp32, 1e8 - 1e8 + 1 = 1
+    pts = np.array([[10.0, 0, 0, 1], [10.0000095, 0, 0, 1], [9.999999, 0, 0, 1]], np.float32)
+    p = params_with_size(W, H, avg_vertexmap=1, filter_sampling=1)
+    ora = oracle_lib.Oracle(p)
+    f = ora.preprocess(pts, None, None, 12, ora.frame())
+    v = f.vertex.reshape(H, W, 4)
+    hit = np.argwhere(v[..., 3] > 0.5)
+    assert len(hit) == 1
+    y, x = hit[0]
+    s = np.float32(0)
+    for q in pts[:, 0]:
+        s = np.float32(q + s)
+    assert v[y, x, 0] == np.float32(s / np.float32(3.0)) and v[y, x, 3] == 1.0
+    # GL initial state (LINEAR, CLAMP_TO_EDGE): the integer coordinate is a texel corner, so the sum spreads over the
+    # four texels that touch it with weight 1/4 each: count 3/4 > 0.5, each of them is "valid" and gets the mean
+    ora2 = oracle_lib.Oracle(params_with_size(W, H, avg_vertexmap=1))
+    f2 = ora2.preprocess(pts, None, None, 12, ora2.frame())
+    v2 = f2.vertex.reshape(H, W, 4)
+    q = np.float32(0.25)
+    assert np.count_nonzero(v2[..., 3] > 0) == 4 and {tuple(h) for h in np.argwhere(v2[..., 3] > 0).tolist()} == \
+        {(y, x), (y + 1, x), (y, x + 1), (y + 1, x + 1)}
+    assert v2[y + 1, x + 1, 3] == 1.0 and v2[y + 1, x + 1, 0] == np.float32(np.float32(s * q) / np.float32(np.float32(3) * q))
+    # bilateral filter on a sphere of constant range 8: every neighbour's "range" is length(vec4) = sqrt(8^2 + 1^2),
+    # w included (bilateral_filter.frag:64), so the filtered range is sqrt(65) whatever the weights are
+    az = (np.arange(W) + 0.5) / W * 2 * np.pi - np.pi
+    el = np.deg2rad(np.linspace(-24.5, 2.5, H))
+    A, E = np.meshgrid(az, el)
+    sph = np.stack([8 * np.cos(A) * np.cos(E), 8 * np.sin(A) * np.cos(E), 8 * np.sin(E), np.ones_like(A)], -1)
+    sph = sph.reshape(-1, 4).astype(np.float32)
+    base = oracle_lib.Oracle(params_with_size(W, H))
+    f0 = base.preprocess(sph, None, None, 12, base.frame())
+    v0 = f0.vertex.reshape(H, W, 4).copy()
+    bf = oracle_lib.Oracle(params_with_size(W, H, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5,
+                                            filter_sampling=1))
+    f1 = bf.preprocess(sph, None, None, 12, bf.frame())
+    v1 = f1.vertex.reshape(H, W, 4).copy()
+    valid = v0[..., 3] > 0.5
+    assert valid.mean() > 0.9 and np.array_equal(v1[..., 3] > 0.5, valid)
+    assert np.abs(v1[valid][:, :3] - v0[valid][:, :3] * np.float32(np.sqrt(65.0) / 8.0)).max() < 2e-5
+    # ... and with use_filtered_vertexmap off the filter's result is dropped (Preprocessing.cpp:234)
+    off = oracle_lib.Oracle(params_with_size(W, H, filter_vertexmap=1, use_filtered_vertexmap=0, bilateral_sigma_space=4.5))
+    f3 = off.preprocess(sph, None, None, 12, off.frame())
+    assert np.array_equal(f3.vertex.reshape(H, W, 4), v0)

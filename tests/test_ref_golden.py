@@ -4,7 +4,10 @@ code involved).  CPU: the oracle reproduces them.  GPU (-m gpu): the HIP path re
 a comparison of the product with the reference's shader arithmetic that does not pass through the oracle.
 Equal VALUES are demanded on every field (a shader transforms directions with a w = 0 column that adds a signed
 zero); records whose normal the GLSL slerp turned into NaN are exempt in nx / ny / nz (documented deviation; none
-occur in this fixture)."""
+occur in this fixture).
+
+tests/golden/ref_filters_180x16.npz holds the same for Preprocessing::process with the optional vertex-map filters on
+(blended K1 + avg_vertexmap.frag, bilateral_filter.frag; both sampling states of `filter_sampling`)."""
 import os
 
 import numpy as np
@@ -15,6 +18,18 @@ from semantic_suma_amd.types import params_with_size
 G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_180x16.npz"))
 W, H = int(G["W"]), int(G["H"])
 P = params_with_size(W, H, max_surfels=1 << 16, max_poses=64)
+
+
+GF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_filters_180x16.npz"))
+FILTER_CASES = {
+    "avg": dict(avg_vertexmap=1),
+    "avg_nearest": dict(avg_vertexmap=1, filter_sampling=1),
+    "bilateral": dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5, bilateral_sigma_range=2.5),
+    "bilateral_nearest": dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5,
+                              bilateral_sigma_range=2.5, filter_sampling=1),
+    "avg_bilateral_nearest": dict(avg_vertexmap=1, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=2.0,
+                                  bilateral_sigma_range=0.5, filter_sampling=1),
+}  # as tests/golden/make_ref_golden.py
 
 
 def eq(a, b, what):
@@ -99,3 +114,40 @@ def test_hip_reproduces_reference_shader_vectors():
         return obj.acc
 
     check(preprocess, update, k6)
+
+
+def check_filters(name, preprocess):
+    """preprocess(timestamp) -> (v, n, s) of the dense scan with FILTER_CASES[name] set"""
+    for t in (0, 12):
+        v, n, s = preprocess(t)
+        eq(v, GF[f"{name}_t{t}_vertex"], f"{name} t={t}: vertex map")
+        eq(n, GF[f"{name}_t{t}_normal"], f"{name} t={t}: normal map")
+        eq(s, GF[f"{name}_t{t}_semantic"], f"{name} t={t}: semantic map")
+    v = GF[f"{name}_t12_vertex"]
+    assert int((v[..., 3] > 0.5).sum()) > 0.8 * W * H and GF["pts"].shape[0] > 4 * W * H  # dense: sums of several points
+
+
+@pytest.mark.parametrize("name", sorted(FILTER_CASES))
+def test_oracle_reproduces_reference_filter_vectors(oracle_lib, name):
+    ora = oracle_lib.Oracle(params_with_size(W, H, max_surfels=1 << 16, max_poses=64, **FILTER_CASES[name]), threads=4)
+
+    def preprocess(t):
+        f = ora.preprocess(GF["pts"], GF["lab"], GF["prob"], t, ora.frame())
+        return f.vertex.copy(), f.normal.copy(), f.semantic.copy()  # the views die with the frame
+
+    check_filters(name, preprocess)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(FILTER_CASES))
+def test_hip_reproduces_reference_filter_vectors(name):
+    from semantic_suma_amd import core
+    ctx = core.Context(params_with_size(W, H, max_surfels=1 << 16, max_poses=64, **FILTER_CASES[name]))
+    pre = core.Preprocessing(ctx)
+
+    def preprocess(t):
+        f = core.Frame(ctx, W, H)
+        pre.process(GF["pts"], f, GF["lab"], GF["prob"], t)
+        return f.download(0), f.download(1), f.download(2)
+
+    check_filters(name, preprocess)

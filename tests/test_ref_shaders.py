@@ -165,11 +165,16 @@ def sequence(oracle_lib, scans):
     dict(update_always=1), dict(unstable_age=1, confidence_threshold=0.3, p_stable=0.8, p_prior=0.4),
     dict(map_max_distance=0.05, map_max_angle=10.0), dict(min_radius=0.05, max_radius=0.2, max_angle=60.0),
     dict(compose_rendering=0), dict(label_offset=0, prob_offset=0), dict(submap_extent=3.0, submap_dimension=2),
+    # the optional vertex-map filters (Preprocessing.cpp:150-236), both texture states of `filter_sampling`
+    dict(avg_vertexmap=1), dict(avg_vertexmap=1, filter_sampling=1),
+    dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=4.5, bilateral_sigma_range=2.5),
+    dict(avg_vertexmap=1, filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=2.0,
+         bilateral_sigma_range=0.5, filter_sampling=1),
 ], ids=lambda o: ",".join(f"{k}={v}" for k, v in o.items()))
 def test_every_stage_with_the_switches_default_xml_leaves_off(oracle_lib, scans, overrides):
     """the branches of update_surfels.vert / init_radiusConf.vert / copy_surfels.vert that config/default.xml does not
     take (weighting and averaging schemes, confidence models, stability off, update_always, tight gates, small
-    submaps), against the compiled reference shaders on a live 7-scan run"""
+    submaps, the vertex-map filters of Preprocessing), against the compiled reference shaders on a live 7-scan run"""
     out = run_sequence(oracle_lib, scans, 7, **overrides)
     assert out["log"]["scans"] == 7 and out["log"]["k9_integrated"] > 1000
 
