@@ -11,4 +11,5 @@ python tools/rocprof_summary.py "$O"/prof/*kernel_trace.csv > "${P}_kernel_trace
 python tools/make_hbm_traffic.py "$O"/pmc_fetch/*counter_collection.csv "$O"/pmc_write/*counter_collection.csv 2048 64 profiles/hbm_traffic.json > "${P}_hbm_traffic_pmc.txt"
 python tools/sq_summary.py "$O"/pmc_sq1/*counter_collection.csv "$O"/pmc_sq2/*counter_collection.csv "$O"/pmc_sq3/*counter_collection.csv > "${P}_sq_summary.txt"
 cp "$O/stress.json" "${P}_stress_50M_surfels_128x4096.json"
+for f in bench_hypotheses.json bench_sequences11.json ingest.json multi_seq.txt; do [ -s "$O/$f" ] && cp "$O/$f" "${P}_$f"; done
 ls -la profiles | tail -20

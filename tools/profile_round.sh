@@ -2,12 +2,12 @@
 # One-call evidence run for profiles/ (inside a gpurun call, ~2 min of GPU time):
 #   gpurun --timeout 1800 -- 'bash tools/profile_round.sh r02'
 # writes gpurun_out/<tag>/: pytest, bench (default and 300 steps), rocprofv3 kernel trace + stats, the two HBM PMC
-# passes and three SQ-counter passes (counter runs WITHOUT any trace domain, as the pool requires) and the
-# 50 M-surfel stress run.  Afterwards, on the build machine:  bash tools/collect_profiles.sh <tag>
+# passes and three SQ-counter passes (counter runs WITHOUT any trace domain, as the pool requires), the
+# 50 M-surfel stress run, the config-3 / config-4 modes, the host-scan hand-over and the multi-pipeline run.  Afterwards, on the build machine:  bash tools/collect_profiles.sh <tag>
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 B="python bench.py --cpu-scans 0 --no-kernel-events --steady-scans 0"
-timeout 600 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
+timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
 timeout 400 python bench.py 2>/dev/null | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
 timeout 300 $B --steps 300 2>/dev/null | tail -1 > "$O/bench_300_steps.json"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --steady-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
@@ -17,4 +17,9 @@ timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VAL
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d "$O/pmc_sq2" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq2.log" 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS -d "$O/pmc_sq3" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq3.log" 2>&1
 timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
+# BASELINE configs[2] / configs[3] on ONE GPU (the driver owns the 8-GPU runs), the host-scan hand-over, 4 pipelines per GPU
+timeout 300 python bench.py --mode hypotheses --steps 40 2>/dev/null | tail -1 > "$O/bench_hypotheses.json"
+timeout 400 python bench.py --mode sequences11 --steps 40 2>/dev/null | tail -1 > "$O/bench_sequences11.json"
+timeout 300 python tools/ingest_bench.py 2>/dev/null | tail -1 > "$O/ingest.json"
+timeout 300 python tools/multi_seq.py 2>/dev/null | tail -1 > "$O/multi_seq.txt"
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; ls "$O"
