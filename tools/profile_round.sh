@@ -21,5 +21,5 @@ timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
 timeout 300 python bench.py --mode hypotheses --steps 40 2>/dev/null | tail -1 > "$O/bench_hypotheses.json"
 timeout 400 python bench.py --mode sequences11 --steps 40 2>/dev/null | tail -1 > "$O/bench_sequences11.json"
 timeout 300 python tools/ingest_bench.py 2>/dev/null | tail -1 > "$O/ingest.json"
-timeout 300 python tools/multi_seq.py 2>/dev/null | tail -1 > "$O/multi_seq.txt"
+timeout 300 python tools/multi_seq.py 4 60 2>/dev/null | tail -1 > "$O/multi_seq.txt"
 cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; ls "$O"
