@@ -1,7 +1,8 @@
 """GPU tests of the multi-GPU runners on ONE device (run with -m gpu): two processes (gloo rendezvous, both on
 device 0) drive the HIP path through semantic_suma_amd.distributed.run_hypotheses and must reach, rank for rank, the
 winners / poses / map of a single process that runs all hypotheses itself; config 4's runner with three
-sequences as concurrent pipelines on one GPU.  The RCCL collective itself needs one GPU per rank: bench.py --gpus N."""
+sequences as concurrent pipelines on one GPU; a world-1 RCCL process group with its collectives running beside the
+pipeline in one process (what each rank of bench.py --gpus N does).  RCCL between ranks needs one GPU per rank: bench.py --gpus N."""
 import hashlib
 import os
 import socket
@@ -100,3 +101,45 @@ def test_bench_contract_with_two_ranks_on_one_device():
     assert d["value"] > 100 and abs(d["value"] - 2 * 6 / (d["ms_per_step"] * 6 / 1000.0)) < 1e-6 * d["value"]
     assert d["roofline"]["kernel"] == "k6_icp_step" and "cpu_baseline" not in d
     assert d["config"]["drift_m"] < 0.5
+
+
+def test_rccl_process_group_beside_the_pipeline():
+    """What every rank of `bench.py --gpus N` (N > 1) does, with N = 1: a torch.distributed process group on RCCL
+    (backend "nccl") lives in the same process as libsuma_hip.so, collectives on CUDA tensors (barrier, all_reduce
+    MAX, all_gather of poses) run between scans, and the pipeline's results do not change.  Fresh interpreter, torch
+    first -- the order bench.py uses (one HIP runtime in the process)."""
+    import subprocess
+    code = f"""
+import os, sys
+sys.path.insert(0, {ROOT!r})
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="{_free_port()}", RANK="0", WORLD_SIZE="1")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+from semantic_suma_amd import core, synth
+from semantic_suma_amd.types import params_with_size
+p = params_with_size({W})
+scans = [synth.generate_scan(k, n_azimuth={W})[:3] for k in range(4)]
+solo = core.SurfelMapping(p, device=0)
+for s in scans: solo.processScan(*s, fixed_iterations=8)
+want = solo.getCurrentPose().copy()
+dist.init_process_group("nccl", device_id=dev)
+pipe = core.SurfelMapping(p, device=0)
+for s in scans:
+    pipe.processScan(*s, fixed_iterations=8)
+    dist.barrier()
+    t = torch.tensor([float(pipe.map.size())], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert int(t.item()) == pipe.map.size()
+    x = torch.as_tensor(pipe.getCurrentPose().copy()).to(dev)
+    outs = [torch.empty_like(x)]
+    dist.all_gather(outs, x)
+    assert np.array_equal(outs[0].cpu().numpy(), pipe.getCurrentPose())
+torch.cuda.synchronize()
+assert np.array_equal(pipe.getCurrentPose(), want), "pose changed beside the process group"
+assert pipe.map.getAllSurfels().tobytes() == solo.map.getAllSurfels().tobytes()
+dist.destroy_process_group()
+print("RCCL_OK", dist.is_nccl_available())
+"""
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "RCCL_OK True" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
