@@ -205,4 +205,20 @@ SDEV void zbuf_min(unsigned long long* __restrict__ addr, unsigned long long key
   if (key < __hip_atomic_load(addr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(addr, key);
 }
 
+/* inclusive prefix sum over the 64 lanes of a wave as DPP moves (six VALU-rate steps; six __shfl_up are six
+ * ds_bpermute round trips in a dependent chain): Kogge-Stone inside each row of 16 (row_shr:1,2,4,8; a lane without
+ * a source keeps old = 0), then lane 15 of rows 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into the upper half
+ * (row_bcast:31) */
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  int x = (int)v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);
+  return (uint32_t)x;
+}
+
+
 #endif

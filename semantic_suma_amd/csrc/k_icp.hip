@@ -108,6 +108,29 @@ __device__ __forceinline__ long long shfl_xor_ll(long long v, int mask) {
   return ((long long)hi << 32) | (unsigned int)lo;
 }
 
+/* lane ^ MASK exchanges inside a row of 16 lanes as DPP moves (VALU rate; __shfl_xor lowers to ds_bpermute_b32, an LDS
+ * crossbar round trip of ~60 cycles, and the butterfly below is a dependent chain of them):
+ *   ^1, ^2  quad_perm [1,0,3,2] / [2,3,0,1];  ^8  row_ror:8;
+ *   ^4      lanes 0-3 / 8-11 of a row take from lane + 4 (row_shl:4), the others from lane - 4 (row_shr:4) */
+template <int MASK>
+__device__ __forceinline__ int dpp_xor(int v) {
+  static_assert(MASK == 1 || MASK == 2 || MASK == 4 || MASK == 8, "row-local exchanges only");
+  if (MASK == 1) return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+  if (MASK == 2) return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+  if (MASK == 8) return __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true);
+  /* both directions with bound_ctrl (a lane without an enabled source reads 0, as in the other three forms), then
+   * the lane picks its side */
+  const int from_up = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0xF, true);   /* row_shl:4: lane + 4 */
+  const int from_down = __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true); /* row_shr:4: lane - 4 */
+  return (threadIdx.x & 4u) ? from_down : from_up;
+}
+template <int MASK>
+__device__ __forceinline__ long long dpp_xor_ll(long long v) {
+  const int lo = dpp_xor<MASK>((int)(v & 0xffffffffll));
+  const int hi = dpp_xor<MASK>((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
 /* Butterfly reduction of 32 per-lane words over a 64-lane wave: at each stage a lane keeps half
  * of its words and trades the other half with its partner, so 32 -> 1 word per lane costs
  * 16+8+4+2+1 exchanges plus one final pairwise add.  Afterwards lane L holds the wave total of
@@ -181,7 +204,7 @@ __device__ __forceinline__ void reduce16_stage(long long (&a)[16], int lane) {
   for (int i = 0; i < H; ++i) {
     long long keep = upper ? a[i + H] : a[i];
     long long send = upper ? a[i] : a[i + H];
-    a[i] = keep + shfl_xor_ll(send, MASK);
+    a[i] = keep + dpp_xor_ll<MASK>(send);
   }
 }
 __device__ __forceinline__ long long wave_reduce16(long long (&a)[16], int lane) {
@@ -189,8 +212,8 @@ __device__ __forceinline__ long long wave_reduce16(long long (&a)[16], int lane)
   reduce16_stage_swap<4, false>(a);
   reduce16_stage<2, 8>(a, lane);
   reduce16_stage<1, 4>(a, lane);
-  long long t = a[0] + shfl_xor_ll(a[0], 2);
-  return t + shfl_xor_ll(t, 1);
+  long long t = a[0] + dpp_xor_ll<2>(a[0]);
+  return t + dpp_xor_ll<1>(t);
 }
 __device__ __forceinline__ int word16_of_lane(int lane) {
   return ((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1);

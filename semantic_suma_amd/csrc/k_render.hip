@@ -313,12 +313,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         }
       }
       /* inclusive prefix of the test counts over the block */
-      uint32_t incl = ntests;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        uint32_t o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl += o;
-      }
+      uint32_t incl = wave_inclusive_scan(ntests);
       if (lane == 63) s_w[1][wave] = incl;
       __syncthreads();
       uint32_t woff = 0, total = 0;

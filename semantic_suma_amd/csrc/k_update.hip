@@ -87,9 +87,7 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
     sum += (uint32_t)(w & 0xffffffffull);
   }
   if (timed_out) atomicOr(fault, 8u);
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) sum += __shfl_xor(sum, m, 64);
-  return sum;
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(sum), 63); /* wave total, DPP (dev_math.h) */
 }
 __device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
                                     uint32_t tile, uint32_t agg, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
