@@ -166,7 +166,7 @@ __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, 
 
 __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
   __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
-  __shared__ int32_t s_rec[RENDER_THREADS][16]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id */
+  __shared__ int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
   __shared__ uint32_t s_incl[RENDER_THREADS];
   __shared__ uint32_t s_w[2][RENDER_WAVES];
   const uint32_t S = a.ds->n_surfels;
