@@ -17,8 +17,8 @@
  *   - every fp32 term is converted to 2^-28 fixed point (round to nearest even, via the
  *     1.5*2^52 double trick) and summed as int64: exact and order independent, so the result is
  *     bit-identical for any reduction tree (and to the CPU oracle);
- *   - per-lane int64 accumulators -> wave butterfly (stages 32 / 16 on v_permlane32/16_swap, the rest
- *     ds_bpermute) -> LDS across the 8 waves -> the block's 32 sums are ADDED into one of ICP_RECORDS (8) rotating
+ *   - per-lane int64 accumulators -> wave butterfly (lane-swap stages on v_permlane32/16_swap, the row-local
+ *     stages as DPP moves) -> LDS across the 8 waves -> the block's 32 sums are ADDED into one of ICP_RECORDS (8) rotating
  *     accumulator records per hypothesis with memory-side 64-bit atomics (exact integers: order immaterial);
  *   - no in-kernel hand-off: the records of launch j are consumed by the PROLOGUE of launch j+1 (kernel
  *     boundary = visibility), where every block redundantly totals them (2 KB), solves the 6x6 system by LDL^T
