@@ -115,6 +115,22 @@ def test_pipeline_with_vertexmap_filters(hip, oracle_lib):
         assert hp.map.size() > 20000
 
 
+def test_vertexmap_filters_switched_on_a_live_context(hip, oracle_lib):
+    """setParameters on a context that was created without the filters: their buffers are allocated on first use"""
+    W = 900
+    pts, lab, prob, _ = get_scan(3, W, True)
+    ctx = hip.Context(params_with_size(W))
+    for ov in (dict(), dict(avg_vertexmap=1, filter_sampling=1),
+               dict(filter_vertexmap=1, use_filtered_vertexmap=1, bilateral_sigma_space=3.0), dict()):
+        p = params_with_size(W, **ov)
+        ctx.set_params(p)
+        ora = oracle_lib.Oracle(p, threads=THREADS)
+        hf = hip.Frame(ctx, W, 64)
+        hip.Preprocessing(ctx).process(pts, hf, lab, prob, 12)
+        of = ora.preprocess(pts, lab, prob, 12, ora.frame())
+        frames_equal(hf, of, f"live switch {ov}")
+
+
 def test_vertexmap_filter_parameter_errors(hip):
     with pytest.raises(hip.SumaError, match="bilateral_sigma_space"):
         hip.Context(params_with_size(900, filter_vertexmap=1))  # default.xml holds no bilateral_sigma_space
