@@ -221,4 +221,30 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 }
 
 
+/* -DSUMA_PHASE_TIMING (tools/phase_timeline.py builds such a library next to the product one): thread 0 of every block
+ * accumulates wall_clock64 (100 MHz) between the stations of its tiles and adds the totals to a per-kernel symbol */
+#ifdef SUMA_PHASE_TIMING
+#define PH_BEGIN unsigned long long ph_t = wall_clock64(), ph_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define PH(k)                                         \
+  do {                                                \
+    if (threadIdx.x == 0) {                           \
+      const unsigned long long now_ = wall_clock64(); \
+      ph_acc[k] += now_ - ph_t;                       \
+      ph_t = now_;                                    \
+    }                                                 \
+  } while (0)
+#define PH_BLOCKS 8192 /* per-block slots: hot global counters would serialise at one memory channel and distort the run */
+#define PH_END(sym)                                                              \
+  do {                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < PH_BLOCKS) {                            \
+      for (int k_ = 0; k_ < 8; ++k_) sym[blockIdx.x][k_] += ph_acc[k_];            \
+      sym[blockIdx.x][8] += 1ull;                                                \
+    }                                                                            \
+  } while (0)
+#else
+#define PH_BEGIN ((void)0)
+#define PH(k) ((void)0)
+#define PH_END(sym) ((void)0)
+#endif
+
 #endif

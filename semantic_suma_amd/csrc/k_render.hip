@@ -142,6 +142,20 @@ __device__ __forceinline__ void surfel_to_sensor(const float* __restrict__ poses
  *                         median surfel covers no pixel centre, the mean box is 3.6 tests, but the mean
  *                         per-wave maximum is 14 -- a lane-per-surfel raster loop ran 7x longer than
  *                         the work it contained. */
+#ifdef SUMA_PHASE_TIMING
+__device__ unsigned long long g_k4_phase[PH_BLOCKS][9];
+/* host: PH_BLOCKS x 9 words (8 phase totals in 10 ns units + the number of launches the block took part in) */
+extern "C" int suma_debug_k4_phases(unsigned long long* host, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k4_phase), sizeof(g_k4_phase));
+  if (e == hipSuccess && reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_k4_phase));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(g_k4_phase));
+  }
+  return (int)e;
+}
+#endif
+
 #define RENDER_THREADS 256
 #define RENDER_WAVES (RENDER_THREADS / 64)
 #define RENDER_BATCH 2
@@ -177,7 +191,9 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
    * head mostly surfels that leave after phase 1a.  Dispatching the expensive tiles first keeps the cheap
    * ones for the kernel's tail. */
   const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
+  PH_BEGIN;
   for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    PH(7); /* loop overhead / previous tile's tail */
     const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
     const uint32_t i = blk0 + threadIdx.x;
     float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
@@ -191,6 +207,10 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
     const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
+#ifdef SUMA_PHASE_TIMING
+    if (live && ts == 0x7fffffff) ph_acc[7] += 1; /* consumes the loads before the stamp */
+#endif
+    PH(0); /* surfel loads arrived */
 #pragma unroll
     for (int sl = 0; sl < 2; ++sl) {
       const RenderSlot& slot = a.slot[sl];
@@ -229,6 +249,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       }
       uint32_t ncand;
       const uint32_t crank = render_block_rank(cand, s_w[0], &ncand);
+      PH(1); /* phase 1a + rank barrier */
       if (cand) {
         float* r = s_cand[crank];
         r[0] = p.x;
@@ -242,6 +263,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         r[8] = __uint_as_float(i);
       }
       __syncthreads();
+      PH(2); /* candidate list written + barrier */
       /* ---- phase 1b: dense lanes ---- */
       uint32_t ntests = 0;
       if (threadIdx.x < ncand) {
@@ -312,6 +334,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
           }
         }
       }
+      PH(3); /* phase 1b */
       /* inclusive prefix of the test counts over the block */
       uint32_t incl = wave_inclusive_scan(ntests);
       if (lane == 63) s_w[1][wave] = incl;
@@ -325,6 +348,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       }
       s_incl[threadIdx.x] = incl + woff;
       __syncthreads();
+      PH(4); /* prefix over the block, two barriers */
       /* ---- phase 2 ---- */
       /* RENDER_BATCH tests per lane and trip: the fragments' keys are computed first, then the (device-
        * coherent, i.e. memory-side) z-buffer reads of the batch are in flight together and the atomics follow
@@ -387,9 +411,12 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
           if (key[u] < cur[u]) atomicMin(&slot.zbuf[pix[u]], key[u]);
       }
       if (k7_key < k7_cur) atomicMin(&a.k7_zbuf[k7_pix], k7_key);
+      PH(5); /* phase 2: pixel tests, z-buffer reads, atomics */
       __syncthreads(); /* the LDS lists are reused by the next slot / iteration */
+      PH(6); /* closing barrier */
     }
   }
+  PH_END(g_k4_phase);
 }
 
 __device__ __forceinline__ uint32_t key_id(unsigned long long key, int tie) {

@@ -475,6 +475,20 @@ __device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, ui
   return r;
 }
 
+#ifdef SUMA_PHASE_TIMING
+__device__ unsigned long long g_k9_phase[PH_BLOCKS][9];
+/* host: PH_BLOCKS x 9 words (8 phase totals in 10 ns units + the number of launches the block took part in) */
+extern "C" int suma_debug_k9_phases(unsigned long long* host, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(g_k9_phase), sizeof(g_k9_phase));
+  if (e == hipSuccess && reset) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_k9_phase));
+    if (e == hipSuccess) e = hipMemset(p, 0, sizeof(g_k9_phase));
+  }
+  return (int)e;
+}
+#endif
+
 __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
   __shared__ float4 s_out[2][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
   __shared__ uint16_t s_slot[2][SUMA_TILE]; /* stable rank -> slot */
@@ -489,12 +503,15 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
   if (a.write_pose && blockIdx.x == 0 && threadIdx.x == 0) write_pose_entry(a.poses_w, a.poses_inv_w, a.pose_idx, a.pose);
   /* the tile whose records wait in LDS for their output offset */
   uint32_t prev_tile = 0xffffffffu, prev_total = 0, buf = 0;
+  PH_BEGIN;
   for (;;) {
+    PH(7); /* loop overhead */
     lds_barrier(); /* s_tile / s_prefix / s_cnt_* of the previous trip have been read */
     if (threadIdx.x == 0)
       s_tile = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lds_barrier();
     const uint32_t tile = s_tile;
+    PH(0); /* ticket: atomic round trip between two barriers */
     uint32_t total = 0;
     if (tile < ntiles) {
       /* lane t handles slots t, K9_THREADS + t, ...: slot order = surfel order = stable order */
@@ -511,6 +528,10 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
       }
 #pragma unroll
       for (int u = 0; u < K9_PER; ++u) pre[u] = k9_prepare(a, in[u]);
+#ifdef SUMA_PHASE_TIMING
+      if (__float_as_uint(in[0].a.x) == 0x7fc12345u) ph_acc[7] += 1; /* consumes the surfel loads before the stamp */
+#endif
+      PH(1); /* surfel loads + prepare issued */
 #pragma unroll
       for (int u = 0; u < K9_PER; ++u) rec[u] = k9_gather(a, pre[u]);
       uint32_t kept = 0;
@@ -530,6 +551,7 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
         eb[u] = __ballot(emit[u]);
         kept += __popcll(__ballot(keep));
       }
+      PH(2); /* pose entry + measurement gather + update arithmetic + LDS record */
       if (lane == 0) {
         s_cnt_keep[wave] = kept; /* S' statistics (parity with the reference's TF count) */
 #pragma unroll
@@ -557,6 +579,7 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
         keep_count += kc;
         lookback_publish(a.status, a.group, tile, total, a.epoch);
       }
+      PH(3); /* ranks (one barrier) + publish */
     }
     /* the PREVIOUS tile's offset: every tile before it was drawn before it and is published without
      * any wait in between, and this block has published everything it holds -- no circular wait; by
@@ -567,6 +590,7 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
         if (threadIdx.x == 0) s_prefix = pre;
       }
       lds_barrier();
+      PH(4); /* look-back collect of the previous tile + barrier */
       const uint32_t prefix = s_prefix, pb = buf ^ 1u;
       /* compacted stream-out: chunk c = (rank, 16-byte part) */
       for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
@@ -577,12 +601,14 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
         const uint32_t tot = prefix + prev_total;
         a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
       }
+      PH(5); /* stream-out of the previous tile issued */
     }
     if (tile >= ntiles) break;
     prev_tile = tile;
     prev_total = total;
     buf ^= 1u;
   }
+  PH_END(g_k9_phase);
   if (threadIdx.x == 0 && keep_count)
     __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (is_finaliser(s_tile, ntiles)) {

@@ -16,8 +16,12 @@
 #include "../../include/suma_hip.h"
 #include "dev_math.h"
 
+#ifndef SUMA_TILE
 #define SUMA_TILE 1024u       /* items per compaction tile = threads per block (16 waves) */
+#endif
+#ifndef SUMA_COMPACT_BLOCKS
 #define SUMA_COMPACT_BLOCKS 512u /* grid of the ticketed compaction kernels: 2 blocks per CU */
+#endif
 #define SUMA_STREAM_BLOCKS 2048u /* grid cap of the grid-stride surfel kernels: 8 blocks of 256 per CU */
 #define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
 #define SUMA_MAX_HYP 64u

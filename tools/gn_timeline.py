@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 csrc = os.path.join(ROOT, "semantic_suma_amd", "csrc")
 lib = os.path.join(ROOT, "tools", "libsuma_hip_timing.bin")
-srcs = [os.path.join(csrc, f) for f in ("k_preprocess.hip", "k_icp.hip", "k_render.hip", "k_update.hip", "suma_api.hip", "suma_ingest.hip", "k_sync.hip")]
+srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip") and f != "suma_dist.hip"]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-w",
                        "-DSUMA_GN_TIMING", "-shared", "-o", lib] + srcs + ["-lpthread"])
 os.environ["SUMA_HIP_LIB"] = lib
