@@ -1393,13 +1393,10 @@ extern "C" int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* p
                                           const float* probs, uint32_t n, int32_t fixed_iterations) {
   if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
   suma_ctx* c = s->c;
-  /* blocking hand-over of a pageable host scan (the reference's glBufferData in Frame::points.assign,
-   * Preprocessing.cpp:123-125): staged on the stream the preprocessing runs on; the overlapped path is
-   * suma_pipeline_prefetch_scan / process_prefetched (suma_ingest.hip) */
-  if (c->side_stream) c->ls = c->side_stream;
-  int r = stage_scan(c, points, labels, probs, n);
-  c->ls = c->stream;
-  if (r) return r;
-  return suma_pipeline_process_scan_device(s, (const suma_float4*)c->scan_points, labels ? c->scan_labels : nullptr,
-                                           probs ? c->scan_probs : nullptr, n, fixed_iterations);
+  /* hand-over of a pageable host scan (the reference's glBufferData in Frame::points.assign,
+   * Preprocessing.cpp:123-125): copied to pinned memory by several threads, uploaded on the copy stream, consumed
+   * behind a device-side dependency (suma_ingest.hip); scans that should be staged AHEAD of their turn go through
+   * suma_pipeline_prefetch_scan / process_prefetched */
+  (void)c;
+  return pipeline_process_host_scan(s, points, labels, probs, n, fixed_iterations);
 }

@@ -16,12 +16,19 @@
  * ~60 us of DMA) takes about as long as processing one, so it needs a head start of two scans to stay hidden.  A slot is refilled (scan k+2) only after the `consumed` event recorded on the compute stream
  * behind scan k has completed: the upload that read the pinned block and the preprocessing kernels that read the
  * device block are both behind it.
+ *
+ * The plain host-pointer entry suma_pipeline_process_scan (pipeline_process_host_scan below) uses the same pieces on
+ * the caller's time line: the scan goes into one of two pinned blocks of its own -- copied by the caller and
+ * COPY_HELPERS helper threads, one core alone needs about a scan's worth of GPU time for 3 MB -- and up through the
+ * copy stream; the call returns as early as the device-pointer entry, so the next call's copy overlaps this scan's
+ * surfel passes.
  */
 #include <string.h>
 
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <vector>
 
 #include "suma_internal.h"
 
@@ -43,10 +50,93 @@ struct IngestSlot {
   hipError_t error;
 };
 
+/* The blocking host-pointer entry copies a scan (~3 MB) into pinned memory on the CALLER's time line: one core moves
+ * that in ~250 us, about a whole scan's worth of GPU time.  A few helper threads that sleep on a condition variable
+ * between scans take a share each. */
+#define COPY_HELPERS 3
+#define COPY_SEGMENTS 3 /* points, labels, probs */
+struct CopySeg {
+  char* dst;
+  const char* src;
+  size_t bytes;
+};
+struct CopyPool {
+  std::mutex mu;
+  std::condition_variable cv, done_cv;
+  std::vector<std::thread> th;
+  CopySeg job[COPY_HELPERS][COPY_SEGMENTS];
+  uint64_t gen[COPY_HELPERS]; /* generation a helper has a job for */
+  uint64_t posted;
+  int pending;
+  bool stop;
+};
+
+static void copy_helper(CopyPool* p, int id) {
+  uint64_t seen = 0;
+  for (;;) {
+    CopySeg j[COPY_SEGMENTS];
+    {
+      std::unique_lock<std::mutex> lk(p->mu);
+      p->cv.wait(lk, [&] { return p->stop || p->gen[id] != seen; });
+      if (p->stop) return;
+      seen = p->gen[id];
+      for (int k = 0; k < COPY_SEGMENTS; ++k) j[k] = p->job[id][k];
+    }
+    for (int k = 0; k < COPY_SEGMENTS; ++k)
+      if (j[k].bytes) memcpy(j[k].dst, j[k].src, j[k].bytes);
+    {
+      std::lock_guard<std::mutex> lk(p->mu);
+      p->pending -= 1;
+    }
+    p->done_cv.notify_one();
+  }
+}
+
+/* share `part` (0 = the caller) of a segment split into COPY_HELPERS + 1 page-aligned shares */
+static CopySeg seg_share(const CopySeg& s, int part) {
+  const size_t parts = COPY_HELPERS + 1;
+  const size_t share = ((s.bytes / parts) + 4095) & ~(size_t)4095;
+  const size_t lo = share * (size_t)part;
+  if (s.bytes == 0 || lo >= s.bytes) return {nullptr, nullptr, 0};
+  const size_t n = (part == (int)parts - 1 || lo + share > s.bytes) ? s.bytes - lo : share;
+  return {s.dst + lo, s.src + lo, n};
+}
+
+/* every segment dst <- src, split over the helpers and the calling thread; one wake-up for the whole scan */
+static void pool_copy(CopyPool* p, const CopySeg* segs, int nseg) {
+  size_t total = 0;
+  for (int k = 0; k < nseg; ++k) total += segs[k].bytes;
+  if (total < (256u << 10) || p->th.empty()) {
+    for (int k = 0; k < nseg; ++k)
+      if (segs[k].bytes) memcpy(segs[k].dst, segs[k].src, segs[k].bytes);
+    return;
+  }
+  {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->posted += 1;
+    p->pending = COPY_HELPERS;
+    for (int h = 0; h < COPY_HELPERS; ++h) {
+      for (int k = 0; k < COPY_SEGMENTS; ++k) p->job[h][k] = (k < nseg) ? seg_share(segs[k], h + 1) : CopySeg{nullptr, nullptr, 0};
+      p->gen[h] = p->posted;
+    }
+  }
+  p->cv.notify_all();
+  for (int k = 0; k < nseg; ++k) {
+    const CopySeg mine = seg_share(segs[k], 0);
+    if (mine.bytes) memcpy(mine.dst, mine.src, mine.bytes);
+  }
+  std::unique_lock<std::mutex> lk(p->mu);
+  p->done_cv.wait(lk, [&] { return p->pending == 0; });
+}
+
 struct Ingest {
   suma_pipeline* s;
   hipStream_t copy_stream;
   IngestSlot slot[INGEST_SLOTS];
+  /* blocking entry (suma_pipeline_process_scan): two staging slots of its own, used alternately */
+  IngestSlot bslot[2];
+  uint32_t bnext;
+  CopyPool pool;
   uint32_t head, tail; /* next slot to process / next slot to fill (counts, slot = count % INGEST_SLOTS) */
   std::mutex mu;
   std::condition_variable cv;
@@ -132,11 +222,22 @@ static int ingest_get(suma_pipeline* s, Ingest** out) {
   for (auto& q : g->slot) {
     memset(&q, 0, sizeof(q));
   }
+  for (auto& q : g->bslot) memset(&q, 0, sizeof(q));
+  g->bnext = 0;
+  g->pool.posted = 0;
+  g->pool.pending = 0;
+  g->pool.stop = false;
+  for (int h = 0; h < COPY_HELPERS; ++h) g->pool.gen[h] = 0;
   HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
   for (auto& q : g->slot) {
     HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
   }
+  for (auto& q : g->bslot) {
+    HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
+  }
+  for (int h = 0; h < COPY_HELPERS; ++h) g->pool.th.emplace_back(copy_helper, &g->pool, h);
   g->worker = std::thread(ingest_main, g);
   s->ingest = g;
   *out = g;
@@ -152,8 +253,21 @@ void ingest_destroy(suma_pipeline* s) {
   }
   g->cv.notify_all();
   if (g->worker.joinable()) g->worker.join();
+  {
+    std::lock_guard<std::mutex> lk(g->pool.mu);
+    g->pool.stop = true;
+  }
+  g->pool.cv.notify_all();
+  for (auto& t : g->pool.th)
+    if (t.joinable()) t.join();
   hipStreamSynchronize(g->copy_stream);
-  for (auto& q : g->slot) {
+  for (IngestSlot* q = g->slot; q != g->slot + INGEST_SLOTS; ++q) {
+    if (q->pinned) hipHostFree(q->pinned);
+    if (q->device) hipFree(q->device);
+    if (q->uploaded) hipEventDestroy(q->uploaded);
+    if (q->consumed) hipEventDestroy(q->consumed);
+  }
+  for (auto& q : g->bslot) {
     if (q.pinned) hipHostFree(q.pinned);
     if (q.device) hipFree(q.device);
     if (q.uploaded) hipEventDestroy(q.uploaded);
@@ -243,4 +357,47 @@ extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_flo
     if (r) return r;
   }
   return suma_pipeline_process_prefetched(s, fixed_iterations);
+}
+
+/* SurfelMapping::processScan with host vectors, as the reference's caller hands them over (SurfelMapping.cpp:175-210):
+ * the scan is copied into pinned memory by the caller and COPY_HELPERS helper threads, uploaded on the copy stream, and
+ * the preprocessing waits for the upload on the device -- the call returns as early as the device-pointer entry does,
+ * so the surfel passes of this scan overlap the next call's copy. */
+int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations) {
+  Ingest* g = nullptr;
+  int r = ingest_get(s, &g);
+  if (r) return r;
+  suma_ctx* c = s->c;
+  {
+    std::lock_guard<std::mutex> lk(g->mu);
+    if (g->head != g->tail) {
+      c->err = "suma_pipeline_process_scan: prefetched scans are waiting (suma_pipeline_process_prefetched comes first)";
+      return SUMA_ERR_INVALID;
+    }
+  }
+  IngestSlot* q = &g->bslot[g->bnext++ & 1u];
+  if (q->consumed_valid) HIP_TRY(c, hipEventSynchronize(q->consumed)); /* the scan before last has read this slot */
+  HIP_TRY(c, slot_reserve(g, q, n));
+  if (n > 0) {
+    CopySeg segs[COPY_SEGMENTS];
+    int nseg = 0;
+    size_t bytes = (size_t)n * sizeof(float4);
+    segs[nseg++] = {q->pinned, (const char*)points, (size_t)n * sizeof(float4)};
+    if (labels) {
+      segs[nseg++] = {q->pinned + labels_offset(n), (const char*)labels, (size_t)n * sizeof(float)};
+      bytes = labels_offset(n) + (size_t)n * sizeof(float);
+    }
+    if (probs) {
+      segs[nseg++] = {q->pinned + probs_offset(n), (const char*)probs, (size_t)n * sizeof(float)};
+      bytes = probs_offset(n) + (size_t)n * sizeof(float);
+    }
+    pool_copy(&g->pool, segs, nseg);
+    HIP_TRY(c, hipMemcpyAsync(q->device, q->pinned, bytes, hipMemcpyHostToDevice, g->copy_stream));
+  }
+  HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
+  r = pipeline_process_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
+                                 probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, fixed_iterations, q->uploaded);
+  q->consumed_valid = (hipEventRecord(q->consumed, c->stream) == hipSuccess);
+  return r;
 }

@@ -232,6 +232,8 @@ int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, co
                                uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done);
 /* suma_ingest.hip */
 void ingest_destroy(suma_pipeline* s);
+int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations);
 
 #define HIP_TRY(ctx, expr)                                                                       \
   do {                                                                                           \
