@@ -850,8 +850,23 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
 }
 
 /* two entry points so that profiles tell the pixel launches from the closing consume-only launch */
-__global__ void __launch_bounds__(ICP_THREADS) k_icp_step(IterArgs g) { icp_iter_body<true>(g); }
-__global__ void __launch_bounds__(ICP_THREADS) k_icp_finish(IterArgs g) { icp_iter_body<false>(g); }
+/* The pointers behind a launch's FIRST loads are leading scalar parameters: with kernarg preloading (Makefile:
+ * -amdgpu-kernarg-preload-count) they arrive in SGPRs with the wave, so the record / state / data-texel loads of the
+ * prologue do not wait for a round trip to the freshly written kernarg segment first.  The struct holds the same values. */
+__global__ void __launch_bounds__(ICP_THREADS)
+    k_icp_step(const long long* pin, const GnState* gin, const float4* Vd, const float4* Nd, const float4* Sd, IterArgs g) {
+  g.pin = pin;
+  g.gin = gin;
+  g.a.Vd = Vd;
+  g.a.Nd = Nd;
+  g.a.Sd = Sd;
+  icp_iter_body<true>(g);
+}
+__global__ void __launch_bounds__(ICP_THREADS) k_icp_finish(const long long* pin, const GnState* gin, IterArgs g) {
+  g.pin = pin;
+  g.gin = gin;
+  icp_iter_body<false>(g);
+}
 
 static IcpArgs make_args(suma_ctx* c) {
   IcpArgs a;
@@ -944,9 +959,9 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   c->gn_launch += 1;
   dim3 grid(pixel ? c->icp_blocks : 1, n_hyp);
   if (pixel)
-    k_icp_step<<<grid, ICP_THREADS, 0, c->ls>>>(g);
+    k_icp_step<<<grid, ICP_THREADS, 0, c->ls>>>(g.pin, g.gin, g.a.Vd, g.a.Nd, g.a.Sd, g);
   else
-    k_icp_finish<<<grid, ICP_THREADS, 0, c->ls>>>(g);
+    k_icp_finish<<<grid, ICP_THREADS, 0, c->ls>>>(g.pin, g.gin, g);
   return hipGetLastError();
 }
 
