@@ -56,9 +56,10 @@ def conf_threshold(p, t):
     return float(ct)
 
 
-def run_sequence(oracle_lib, scans, n_scans, **overrides):
+def run_sequence(oracle_lib, scans, n_scans, size=None, **overrides):
     """One oracle pipeline run, every stage checked against the compiled reference shaders on the way."""
-    p = params_with_size(W, H, max_surfels=1 << 19, **overrides)
+    W, H = size if size else (globals()["W"], globals()["H"])
+    p = params_with_size(W, H, max_surfels=1 << 21 if size else 1 << 19, **overrides)
     pipe = oracle_lib.OraclePipeline(p)
     ref = pyref.Ref(p)
     log = {"scans": 0, "k9_integrated": 0, "k9_dropped": 0, "quads": 0, "extractions": 0, "origin_shifts": 0, "slerp_nan": 0}
@@ -177,6 +178,13 @@ def test_every_stage_with_the_switches_default_xml_leaves_off(oracle_lib, scans,
     submaps, the vertex-map filters of Preprocessing), against the compiled reference shaders on a live 7-scan run"""
     out = run_sequence(oracle_lib, scans, 7, **overrides)
     assert out["log"]["scans"] == 7 and out["log"]["k9_integrated"] > 1000
+
+
+def test_every_stage_at_the_bench_geometry(oracle_lib, scans):
+    """the same teacher-forced comparison at 64x2048 (BASELINE configs[1]: the geometry bench.py times), 4 scans"""
+    out = run_sequence(oracle_lib, scans, 4, size=(2048, 64))
+    log = out["log"]
+    assert log["scans"] == 4 and log["k9_integrated"] > 50000 and log["quads"] > 300000, log
 
 
 def test_every_stage_along_a_sequence(sequence):
