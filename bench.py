@@ -4,7 +4,9 @@
 A step = one scan through SurfelMapping::processScan (K1-K3 preprocessing, model rendering, 10
 Gauss-Newton ICP iterations + the statistics pass, map update K7-K11, post-update rendering) on a
 64x2048 range image with semantic-weighted ICP (BASELINE.json configs[1]); scans are synthetic
-(semantic_suma_amd/synth.py) and already resident in HBM when the timed region starts.
+(semantic_suma_amd/synth.py) and already resident in HBM when the timed region starts.  configs[1] is a FULL
+sequence, so the timed steps come after an untimed pre-roll of the same sequence (--preroll, default 300 scans)
+that brings the map to its steady size; the rate of the first scans is reported beside it as `cold_start`.
 N > 1 (launched by torch.distributed.run, one process per GPU): every rank runs its own
 independent sequence (sequence sharding, weak scaling) and the poses are gathered once over RCCL.
 
@@ -49,6 +51,40 @@ def hbm_traffic(label, width, height):
         return None if k is None else float(k["hbm_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         return None
+
+
+def adapter_path(scans, W, H, iterations):
+    """compile and run tools/adapter_bench.cpp on the first scans of the sequence (a process of its own beside this
+    one: its contexts are created after the timed region is over).  None if no compiler is at hand."""
+    import shutil
+    import subprocess
+    import tempfile
+    cxx = shutil.which("g++") or shutil.which("c++") or shutil.which("hipcc")
+    if cxx is None:
+        return None
+    tmp = tempfile.mkdtemp(prefix="suma_adapter_")
+    try:
+        for k, sc in enumerate(scans):
+            pts, lab, prob = sc[4]
+            np.ascontiguousarray(pts, dtype="<f4").tofile(os.path.join(tmp, f"{k:06d}.bin"))
+            np.ascontiguousarray(lab, dtype="<f4").tofile(os.path.join(tmp, f"{k:06d}.lab"))
+            np.ascontiguousarray(prob, dtype="<f4").tofile(os.path.join(tmp, f"{k:06d}.prob"))
+        exe = os.path.join(tmp, "adapter_bench")
+        libdir = os.path.join(ROOT, "semantic_suma_amd")
+        subprocess.check_call([cxx, "-std=c++11", "-O2", "-I", os.path.join(ROOT, "include"),
+                               os.path.join(ROOT, "tools", "adapter_bench.cpp"), "-o", exe, "-L", libdir, "-lsuma_hip",
+                               "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], stderr=subprocess.DEVNULL)
+        res = subprocess.run([exe, tmp, str(len(scans)), str(W), str(H), str(iterations)], capture_output=True,
+                             timeout=240)
+        if res.returncode != 0:
+            print(f"adapter_bench failed ({res.returncode}): {res.stderr.decode()[-300:]}", file=sys.stderr)
+            return None
+        return json.loads(res.stdout.decode().strip().splitlines()[-1])
+    except (OSError, subprocess.SubprocessError, ValueError) as e:
+        print(f"adapter_bench not run: {e!r}", file=sys.stderr)
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run_other_mode(args, rank, local_rank, world, coll_dev):
@@ -145,8 +181,11 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the untimed per-kernel HIP-event pass")
     ap.add_argument("--profile-scans", type=int, default=20, help="scans of the untimed per-kernel pass")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
-    ap.add_argument("--steady-scans", type=int, default=300,
-                    help="scans of the untimed continuation that measures the steady state (0 = skip)")
+    ap.add_argument("--preroll", type=int, default=300,
+                    help="scans of the same sequence processed (untimed) before the timed region, so that the map has its "
+                         "steady size; 0 = time the sequence from its first scan (e.g. --steps 4541 --preroll 0)")
+    ap.add_argument("--adapter-scans", type=int, default=120,
+                    help="scans of the class-by-class adapter path timing (tools/adapter_bench.cpp; 0 = skip)")
     ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11"],
                     help="single: BASELINE configs[1] (the bench contract); hypotheses: configs[2], 8 ICP hypotheses per scan "
                          "sharded over the ranks; sequences11: configs[3], the 11 KITTI sequence lengths (scaled) LPT-assigned")
@@ -191,22 +230,30 @@ def main():
     ctx = pipe.ctx
 
     # ---- synthetic sequence of this rank (its own stretch of the trajectory), uploaded to HBM
+    # Order of a run: Wu warm-up scans | K scans timed from the cold start (extra key `cold_start`) | untimed pre-roll
+    # until `--preroll` scans have gone through (the map reaches its steady size: the active area is bounded by the
+    # submap window, SurfelMap.cpp:667-677) | the K TIMED scans of the contract (`value`) | E scans with every kernel
+    # group bracketed.  BASELINE configs[1] is a FULL sequence: its rate is the steady-state rate, not the rate of
+    # the first scans on a near-empty map (round-2 review).  --preroll 0 times the sequence from its first scan.
     k0 = 400 * rank
     scans = []
     t_gen = time.perf_counter()
     E = 0 if args.no_kernel_events else max(0, min(args.profile_scans, K))
-    SS = max(0, args.steady_scans) if (rank == 0 and world == 1) else 0
+    PR = max(0, args.preroll)
+    cold = PR >= Wu + K + 20          # room for a separate cold-start measurement in front of the pre-roll
+    n_before = max(PR, Wu)            # scans processed before the timed region starts
+    total = n_before + K + E
     seq = None
     if kitti_dir:
         from semantic_suma_amd import kitti
         seq = kitti.Sequence(kitti_dir)
-    for k in range(Wu + K + E + SS):
+    for k in range(total):
         if seq is not None:
             pts, lab, prob = seq[(k0 + k) % len(seq)]
         else:
             pts, lab, prob, _ = synth.generate_scan(k0 + k, n_azimuth=W, height=H)
         scans.append((ctx.device_array(pts), ctx.device_array(lab), ctx.device_array(prob), pts.shape[0],
-                      (pts, lab, prob) if (rank == 0 and k < args.cpu_scans) else None))
+                      (pts, lab, prob) if (rank == 0 and k < max(args.cpu_scans, args.adapter_scans)) else None))
     t_gen = time.perf_counter() - t_gen
     n_points = float(np.mean([s[3] for s in scans]))
 
@@ -216,16 +263,31 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    for k in range(Wu):
-        pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+    def run(a, b):
+        for k in range(a, b):
+            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+
+    run(0, Wu)
+    cold_start = None
+    done = Wu
+    if cold:
+        ctx.synchronize()
+        tc = time.perf_counter()
+        run(Wu, Wu + K)
+        ctx.synchronize()
+        tc = time.perf_counter() - tc
+        cold_start = {"value": K / tc, "unit": "scans/s", "ms_per_step": 1000.0 * tc / K, "scans": K, "after_scans": Wu,
+                      "map_surfels_end": pipe.map.size()}
+        done = Wu + K
+    run(done, n_before)
+    map_size_start = pipe.map.size()
     # timed region: only the Gauss-Newton chain (the dominant kernel) is bracketed by HIP events -- one event
     # pair per chain of identical launches, on every 4th scan (an event record costs the stream a ~6 us bubble)
     ctx.profile(3)
     ctx.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for k in range(Wu, Wu + K):
-        pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+    run(n_before, n_before + K)
     poses = gather_poses(pipe.getCurrentPose(), device=coll_dev) if world > 1 else None
     barrier()
     elapsed = time.perf_counter() - t0
@@ -243,27 +305,11 @@ def main():
     if E:
         ctx.profile(1)
         ctx.profile_reset()
-        for k in range(Wu + K, Wu + K + E):
-            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
+        run(n_before + K, n_before + K + E)
         kernels = ctx.profile_get()
     ctx.profile(0)
-    # steady state: BASELINE configs[1] is a FULL sequence; the timed region above covers its first scans, while the
-    # map is still growing.  Continue the same sequence (not timed by the driver) and time the last scans of it.
-    steady = None
-    if SS >= 40:
-        lead = SS - min(200, SS // 2)
-        for k in range(Wu + K + E, Wu + K + E + lead):
-            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
-        ctx.synchronize()
-        ts = time.perf_counter()
-        for k in range(Wu + K + E + lead, Wu + K + E + SS):
-            pipe.processScanDevice(*scans[k][:4], fixed_iterations=args.icp_iterations)
-        ctx.synchronize()
-        ts = time.perf_counter() - ts
-        steady = {"value": (SS - lead) / ts, "unit": "scans/s", "ms_per_step": 1000.0 * ts / (SS - lead),
-                  "scans": SS - lead, "after_scans": Wu + K + E + lead, "map_surfels": pipe.map.size()}
     if seq is None:  # synthetic trajectory: known ground truth
-        gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + Wu + K - 1)
+        gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + n_before + K - 1)
         drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
     else:
         drift = float("nan")
@@ -279,12 +325,15 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "kitti" if seq is not None else "synthetic",
         "config": {"workload": f"BASELINE configs[1]: synthetic KITTI-like sequence, {H}x{W} range images, "
                                f"semantic-weighted ICP ({args.icp_iterations} GN iterations + stats pass) + surfel "
-                               "fusion, one sequence per GPU, scans resident in HBM",
-                   "points_per_scan": round(n_points), "map_surfels_end": map_size, "drift_m": round(drift, 4),
+                               "fusion, one sequence per GPU, scans resident in HBM; timed after "
+                               f"{n_before} untimed scans of the same sequence ({Wu} warm-up + pre-roll to the steady "
+                               f"map size: {map_size_start} surfels at the start of the timed region)",
+                   "points_per_scan": round(n_points), "preroll_scans": n_before, "map_surfels_start": map_size_start,
+                   "map_surfels_end": map_size, "drift_m": round(drift, 4),
                    "parallelism": f"sequence-sharded x{world}" if world > 1 else "single GPU"},
     }
-    if steady is not None:
-        out["steady_state"] = steady
+    if cold_start is not None:
+        out["cold_start"] = cold_start  # the first K scans of the sequence (growing map): NOT the headline
 
     def derive(ks):
         for k in ks:
@@ -329,7 +378,7 @@ def main():
     if world == 1 and args.cpu_scans > 0:
         from oracle import pyoracle
         variant = "native" if pyoracle.build_native() else ""
-        n_cpu = min(args.cpu_scans, Wu + K)
+        n_cpu = min(args.cpu_scans, total)
 
         def time_oracle(threads):
             op = pyoracle.OraclePipeline(p, variant=variant, threads=threads)
@@ -349,6 +398,13 @@ def main():
                                "sample": f"{sample}, OpenMP, {threads} threads of {ncores} host cores"}
         out["cpu_baseline_single_thread"] = {"value": time_oracle(1), "unit": "scans/s", "cores": 1, "kind": "port",
                                              "sample": f"{sample}, one thread"}
+    # ---- what a host pays that does NOT use the scan pipeline: the class-by-class call sequence of the reference's
+    #      processScan on the adapter classes (include/suma_adapter.hpp), the phase API with (empty) loop-closure hooks,
+    #      and the one-call pipeline -- one C++ driver, the same host vectors (tools/adapter_bench.cpp)
+    if world == 1 and args.adapter_scans > 0:
+        ap_res = adapter_path(scans[:min(args.adapter_scans, total)], W, H, args.icp_iterations)
+        if ap_res is not None:
+            out["adapter_path"] = ap_res
     print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -306,5 +306,75 @@ class SurfelMap {
   Context& ctx_;
 };
 
+/* src/core/SurfelMapping.h: the per-scan sequencing (SurfelMapping.cpp:175-210) on the scan pipeline of the library --
+ * K1-K3 on a side stream, the Gauss-Newton chain resident on the device, K7 / K8 fused into the passes around them,
+ * renders de-duplicated.  processScan keeps the reference's shape: integrateLoopClosures and checkLoopClosure stay the
+ * maintainer's functions (pose graph, candidate search, gtsam: untouched) and call the hooks below for their device
+ * parts.  Poses cross as column-major double[16] (Eigen::Matrix4d::data()). */
+class SurfelMapping {
+ public:
+  explicit SurfelMapping(const suma_params& p, int device = 0) {
+    if (suma_pipeline_create(&p, device, &s_) != SUMA_OK)
+      throw std::runtime_error(std::string("suma_pipeline_create: ") + suma_last_error(nullptr));
+  }
+  ~SurfelMapping() { suma_pipeline_destroy(s_); }
+  SurfelMapping(const SurfelMapping&) = delete;
+  SurfelMapping& operator=(const SurfelMapping&) = delete;
+
+  /* processScan(const rv::Laserscan&), SurfelMapping.cpp:175-210.  The two std::function hooks are where the
+   * reference calls integrateLoopClosures() (:179) and checkLoopClosure() (:196); leave them empty for
+   * close-loops = false.  fixed_iterations = 0: the stopping tests of LieGaussNewton decide. */
+  template <class Before, class Between>
+  void processScan(const suma_float4* points, const float* labels, const float* probs, uint32_t n, Before integrate,
+                   Between check_loop_closure, int32_t fixed_iterations = 0) {
+    integrate(*this);                                                                            /* :179 */
+    chk(suma_pipeline_begin_scan(s_, points, labels, probs, n), "SurfelMapping::initialize/preprocess"); /* :181-187 */
+    chk(suma_pipeline_update_pose(s_, fixed_iterations), "SurfelMapping::updatePose");          /* :192 */
+    if (timestamp() > 0) check_loop_closure(*this);                                              /* :196 */
+    chk(suma_pipeline_update_map(s_), "SurfelMapping::updateMap");                               /* :201, :209 */
+  }
+  void processScan(const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                   int32_t fixed_iterations = 0) {
+    chk(suma_pipeline_process_scan(s_, points, labels, probs, n, fixed_iterations), "SurfelMapping::processScan");
+  }
+  /* ---- device parts of checkLoopClosure ---- */
+  /* :546-574, a tracked closure verified again; on success the caller sets currentPose_old_ = out.pose_old (:581) */
+  suma_loop_track trackLoopClosure(double min_valid = 0.2, double max_outlier = 0.85, double max_diff = 0.1) {
+    suma_loop_track t;
+    chk(suma_pipeline_track_loop_closure(s_, min_valid, max_outlier, max_diff, &t), "checkLoopClosure (tracking)");
+    return t;
+  }
+  /* :679-757, a candidate verified from n_init initial guesses (16 doubles each) */
+  std::vector<suma_loop_result> verifyLoopClosure(const double* pose_prior, const double* initializations,
+                                                  uint32_t n_init, float min_valid = 0.2f, float max_outlier = 0.85f) {
+    std::vector<suma_loop_result> out(n_init);
+    chk(suma_pipeline_verify_loop_closure(s_, pose_prior, initializations, n_init, min_valid, max_outlier, out.data()),
+        "checkLoopClosure (candidates)");
+    return out;
+  }
+  void setCurrentPoseOld(const double* pose_old) { chk(suma_pipeline_set_pose_old(s_, pose_old), "currentPose_old_"); }
+  /* ---- integrateLoopClosures, :211-250: casted_poses (16 floats each), difference ---- */
+  void integrateLoopClosures(const std::vector<float>& casted_poses, const double* difference) {
+    chk(suma_pipeline_integrate_loop_closures(s_, casted_poses.data(), (uint32_t)(casted_poses.size() / 16), difference),
+        "SurfelMapping::integrateLoopClosures");
+  }
+  /* which: 0 currentPose_, 1 currentPose_old_, 2 currentPose_new_, 3 lastPose_old_, 4 lastPose_ */
+  void getPose(int which, double* pose16) const { suma_pipeline_get_pose(s_, which, pose16); }
+  void getCurrentPose(double* pose16) const { suma_pipeline_pose(s_, pose16); }
+  suma_icp_stats resultNew() {
+    suma_icp_stats st;
+    chk(suma_pipeline_result_new(s_, &st), "result_new_");
+    return st;
+  }
+  uint32_t timestamp() const { return suma_pipeline_timestamp(s_); }
+  uint32_t trackLoss() const { return suma_pipeline_track_loss(s_); }
+  suma_pipeline* get() const { return s_; }
+  suma_ctx* ctx() const { return suma_pipeline_ctx(s_); }
+
+ private:
+  void chk(int rc, const char* what) const { check(suma_pipeline_ctx(s_), rc, what); }
+  suma_pipeline* s_{nullptr};
+};
+
 }  // namespace suma_hip
 #endif

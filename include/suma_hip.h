@@ -55,7 +55,12 @@ int suma_ctx_create(const suma_params* params, int hip_device, suma_ctx** out);
 void suma_ctx_destroy(suma_ctx* ctx);
 int suma_set_params(suma_ctx* ctx, const suma_params* params);
 int suma_synchronize(suma_ctx* ctx);
-/* the hipStream_t all work of this ctx is enqueued on (for event timing by the caller) */
+/* the hipStream_t the work of this ctx is enqueued on (for event timing by the caller).  One exception: a scan
+ * pipeline runs the preprocessing K1-K3 of a scan on a side stream of its own (it overlaps the surfel passes of the
+ * previous scan) and joins it to this stream before the first reader.  Consequence for suma_pipeline_*_device: the scan
+ * buffers must be COMPLETE when the call is made -- work the caller has enqueued on this stream to produce them is not
+ * waited for by the side stream (synchronise it first, or stage through suma_pipeline_prefetch_scan, whose upload the
+ * preprocessing does wait for).  SUMA_NO_SIDE_STREAM=1 in the environment keeps everything on this one stream. */
 void* suma_ctx_stream(suma_ctx* ctx);
 
 /* ---- frames: Frame::Frame / Frame::copy (Frame.h:26-61); which = SUMA_MAP_* */
@@ -177,6 +182,38 @@ int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* points, con
 int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_iterations);
 int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_float4* points, const float* labels,
                                      const float* probs, uint32_t n, int32_t fixed_iterations);
+/* ---- the phases of SurfelMapping::processScan as calls of their own (SurfelMapping.cpp:175-204), for hosts that run
+ *      loop closures between them -- config/default.xml:71 ships close-loops = true, and then processScan is
+ *        integrateLoopClosures (:179) -> initialize + preprocess (:181-187) -> updatePose (:192) ->
+ *        checkLoopClosure (:196) -> updateMap (:201) -> timestamp_ += 1 (:209).
+ *      begin_scan = initialize + preprocess (K1-K3 on the side stream, the pre-ICP render(pose_old, pose_new));
+ *      update_pose = updatePose (no-op while timestamp == 0, as :190); update_map = updateMap + timestamp_ += 1.
+ *      suma_pipeline_process_scan* IS these three back to back: same launches, same side stream, fused K7 / K8, lazy
+ *      statistics and render de-duplication -- a host with loop closures on loses none of them.
+ *      Between update_pose and update_map the host may call suma_pipeline_verify_loop_closure /
+ *      suma_pipeline_track_loop_closure (the device sides of checkLoopClosure) and suma_pipeline_set_pose_old;
+ *      before begin_scan, suma_pipeline_integrate_loop_closures. */
+int suma_pipeline_begin_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                             uint32_t n);
+int suma_pipeline_begin_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                                    const float* d_probs, uint32_t n);
+/* the oldest scan staged with suma_pipeline_prefetch_scan */
+int suma_pipeline_begin_prefetched(suma_pipeline* s);
+int suma_pipeline_update_pose(suma_pipeline* s, int32_t fixed_iterations);
+int suma_pipeline_update_map(suma_pipeline* s);
+/* integrateLoopClosures (SurfelMapping.cpp:211-250) once the pose graph has been optimised: map_->updatePoses(poses)
+ * (:236), currentPose_ = difference * currentPose_ (:239), currentPose_new_ = currentPose_old_ = currentPose_ (:243).
+ * poses16: n x 16 floats (casted_poses); difference: poses_opt[beforeID_] * beforeOptimizationPose_^-1 (:229). */
+int suma_pipeline_integrate_loop_closures(suma_pipeline* s, const float* poses16, uint32_t n, const double difference[16]);
+/* currentPose_old_ = ... (SurfelMapping.cpp:582 after a tracked closure, :744 after a verified candidate): the pose the
+ * NEXT scan's render() uses for the inactive ("old") part of the map */
+int suma_pipeline_set_pose_old(suma_pipeline* s, const double pose_old[16]);
+/* which: 0 currentPose_, 1 currentPose_old_, 2 currentPose_new_, 3 lastPose_old_ (:456), 4 lastPose_ */
+int suma_pipeline_get_pose(const suma_pipeline* s, int which, double pose[16]);
+/* result_new_ of updatePose (:417-423): the statistics pass of the current scan (resolves the lazy read-back) --
+ * what checkLoopClosure compares candidates against (:538-539, :582, :727-729) */
+int suma_pipeline_result_new(suma_pipeline* s, suma_icp_stats* st);
+
 int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
 int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
 int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);
@@ -207,6 +244,38 @@ int suma_loop_closure_verify(suma_ctx* ctx, const suma_frame* current, const dou
                              const double* initializations, uint32_t n_init, const float pose_new[16],
                              float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
                              suma_loop_result* out);
+
+/* the same on a pipeline's own state between suma_pipeline_update_pose and suma_pipeline_update_map: current frame,
+ * currentPose_new_ and getConfidenceThreshold() are the pipeline's (SurfelMapping.cpp:679-719) */
+int suma_pipeline_verify_loop_closure(suma_pipeline* s, const double pose_prior[16], const double* initializations,
+                                      uint32_t n_init, float min_valid_ratio, float max_outlier_ratio,
+                                      suma_loop_result* out);
+
+/* ---- the other device part of checkLoopClosure: re-verifying a closure that is being tracked, on the scans that
+ *      follow its detection (SurfelMapping.cpp:546-574): render the inactive map from lastPose_old_, minimise from
+ *      lastIncrement_, gate on the valid / outlier ratios of the objective as the minimisation left it (:557-558) and on
+ *      |log(lastIncrement_) - log(increment_old)| (:561-563; SE3::log, lie_algebra.cpp:36-71), then render the composed
+ *      view at lastPose_old_ * increment_old and evaluate the objective at identity against it (:566-572).  The
+ *      reference's gates are the literals 0.2 / 0.85 / 0.1. */
+typedef struct suma_loop_track {
+  double increment_old[16];      /* gn_->pose() (:560) */
+  suma_icp_stats after_minimize; /* objective_->valid() / outlier() / inlier() / invalid() after minimize (:557-558) */
+  float increment_difference;    /* (:561) */
+  int32_t passed;                /* (:563) */
+  double pose_old[16];           /* lastPose_old_ * increment_old (:564, :581): what currentPose_old_ becomes */
+  suma_icp_stats composed;       /* jacobianProducts at identity against composedFrame (:570-572); zero if !passed */
+  double JtJ[36];
+} suma_loop_track;
+int suma_loop_closure_track(suma_ctx* ctx, const suma_frame* current, const double last_pose_old[16],
+                            const double last_increment[16], const float pose_new[16], float conf_threshold,
+                            double min_valid_ratio, double max_outlier_ratio, double max_increment_difference,
+                            suma_loop_track* out);
+/* on a pipeline's own state (lastPose_old_, lastIncrement_, currentPose_new_, current frame); the reference's
+ * gates are 0.2, 0.85, 0.1 */
+int suma_pipeline_track_loop_closure(suma_pipeline* s, double min_valid_ratio, double max_outlier_ratio,
+                                     double max_increment_difference, suma_loop_track* out);
+/* SE3::log (lie_algebra.cpp:36-71), host side: x = (v, omega) */
+void suma_se3_log(const double T[16], double x[6]);
 
 /* ---- device scratch for callers that keep scans resident in HBM (bench, replay) */
 int suma_device_alloc(suma_ctx* ctx, uint64_t bytes, void** d_ptr);

@@ -1,8 +1,10 @@
 /*
  * oracle/o_pipeline.c -- TEST INFRASTRUCTURE (CPU oracle).
  * Context / frame management and the per-scan sequencing of SurfelMapping::processScan
- * (reference src/core/SurfelMapping.cpp:175-210, 323-358, 372-476, 797-804), without loop closures
- * (SurfelMapping.cpp:527-795 is SURVEY 8(f)-1, "next").
+ * (reference src/core/SurfelMapping.cpp:175-210, 323-358, 372-476, 797-804) in its three phases, the pose
+ * bookkeeping of integrateLoopClosures (:211-250) and the two device-side parts of checkLoopClosure (:546-574 a
+ * tracked closure verified again, :662-757 a candidate verified from three initial guesses).  The candidate
+ * search, the pose graph and its optimiser (gtsam) are not restated: a test scripts their outputs.
  */
 #include "o_ctx.h"
 
@@ -53,6 +55,7 @@ struct ora_pipeline {
   ora_ctx* c;
   ora_frame *last_frame, *current_frame, *current_model, *last_model;
   double current_pose[16], last_pose[16], pose_old[16], pose_new[16], last_increment[16];
+  double last_pose_old[16]; /* lastPose_old_, SurfelMapping.cpp:456 */
   uint32_t timestamp;
   float log_unstable;
   suma_icp_stats stats;
@@ -91,6 +94,7 @@ ora_pipeline* ora_pipeline_create(const suma_params* p) {
   o_eye(s->pose_old);
   o_eye(s->pose_new);
   o_eye(s->last_increment);
+  o_eye(s->last_pose_old);
   /* SurfelMapping.cpp:108-109 */
   float p_unstable = 0.1f;
   s->log_unstable = (float)log((double)(p_unstable / (1.0f - p_unstable)));
@@ -180,13 +184,15 @@ static void o_update_pose(ora_pipeline* s, int32_t fixed_iterations) {
   double np[16];
   o_mul4(s->current_pose, increment, np);
   memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->last_pose_old, s->pose_old, sizeof(np)); /* :456 */
   memcpy(s->pose_old, np, sizeof(np));
   memcpy(s->pose_new, np, sizeof(np));
   memcpy(s->last_increment, increment, sizeof(increment));
 }
 
-void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
-                               uint32_t n, int32_t fixed_iterations) {
+/* initialize() + preprocess(), SurfelMapping.cpp:181-187 */
+void ora_pipeline_begin_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                             uint32_t n) {
   ora_ctx* c = s->c;
   /* initialize(), SurfelMapping.cpp:323-331 */
   ora_frame* t = s->last_frame;
@@ -201,11 +207,157 @@ void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const
   o_cast(s->pose_old, po);
   o_cast(s->pose_new, pn);
   ora_map_render(c, po, pn, o_conf_threshold(s), s->last_model);
+}
+/* :190-193 */
+void ora_pipeline_update_pose(ora_pipeline* s, int32_t fixed_iterations) {
   if (s->timestamp > 0) o_update_pose(s, fixed_iterations);
-  /* updateMap(), :797-804 */
+}
+/* updateMap(), :797-804, and timestamp_ += 1 (:209) */
+void ora_pipeline_update_map(ora_pipeline* s) {
+  ora_ctx* c = s->c;
   float pc[16];
   o_cast(s->current_pose, pc);
   ora_map_update(c, pc, s->current_frame);
   ora_map_render(c, pc, pc, o_conf_threshold(s), s->current_model);
   s->timestamp += 1;
+}
+void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations) {
+  ora_pipeline_begin_scan(s, points, labels, probs, n);
+  ora_pipeline_update_pose(s, fixed_iterations);
+  ora_pipeline_update_map(s);
+}
+
+/* integrateLoopClosures, SurfelMapping.cpp:211-250, the part behind the optimiser's future: poses16 = casted_poses,
+ * difference = poses_opt[beforeID_] * beforeOptimizationPose_.inverse() (:229) */
+void ora_pipeline_integrate_loop_closures(ora_pipeline* s, const float* poses16, uint32_t n, const double difference[16]) {
+  ora_map_update_poses(s->c, poses16, n); /* :236 */
+  double np[16];
+  o_mul4(difference, s->current_pose, np); /* :239 */
+  memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->pose_old, np, sizeof(np)); /* :243 */
+  memcpy(s->pose_new, np, sizeof(np));
+}
+void ora_pipeline_set_pose_old(ora_pipeline* s, const double pose_old[16]) { memcpy(s->pose_old, pose_old, 16 * sizeof(double)); }
+void ora_pipeline_get_pose(const ora_pipeline* s, int which, double pose[16]) {
+  const double* src[5] = {s->current_pose, s->pose_old, s->pose_new, s->last_pose_old, s->last_pose};
+  memcpy(pose, src[which], 16 * sizeof(double));
+}
+
+/* SE3::log, lie_algebra.cpp:36-71 */
+void ora_se3_log(const double T[16], double x[6]) {
+  /* R(r, c) = T[4 * c + r]; R.trace() adds the diagonal in order */
+  const double d = 0.5 * (((T[0] + T[5]) + T[10]) - 1.0); /* :44 */
+  double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};             /* omega_skew, row-major */
+  for (int i = 0; i < 6; ++i) x[i] = 0.0;
+  if (d < 1 - 1e-10) { /* :47 */
+    const double theta = acos(d);
+    const double f = theta / (2 * sin(theta)); /* :49 */
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) W[3 * r + cc] = f * (T[4 * cc + r] - T[4 * r + cc]);
+    x[3] = W[3 * 2 + 1]; /* :51-53 */
+    x[4] = W[3 * 0 + 2];
+    x[5] = W[3 * 1 + 0];
+  }
+  const double theta = sqrt((x[3] * x[3] + x[4] * x[4]) + x[5] * x[5]); /* :56 */
+  const double t[3] = {T[12], T[13], T[14]};
+  x[0] = t[0];
+  x[1] = t[1];
+  x[2] = t[2];
+  if (fabs(theta) > 1e-10) { /* :60 */
+    const double half_theta = 0.5 * theta;
+    const double alpha = -0.5;
+    const double beta = 1 / (theta * theta) * (1 - theta * cos(half_theta) / (2 * sin(half_theta))); /* :64 */
+    double W2[9], Vi[9];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc)
+        W2[3 * r + cc] = (W[3 * r] * W[cc] + W[3 * r + 1] * W[3 + cc]) + W[3 * r + 2] * W[6 + cc];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) Vi[3 * r + cc] = ((r == cc ? 1.0 : 0.0) + alpha * W[3 * r + cc]) + beta * W2[3 * r + cc];
+    for (int r = 0; r < 3; ++r) x[r] = (Vi[3 * r] * t[0] + Vi[3 * r + 1] * t[1]) + Vi[3 * r + 2] * t[2]; /* :67 */
+  }
+}
+
+/* checkLoopClosure, the candidate loop (SurfelMapping.cpp:679-757): render the inactive map from pose_prior, minimise
+ * from every initial guess, and for guesses that pass the ratio gates render the composed view and evaluate the
+ * objective at identity against it.  As in the reference the objective keeps pointing at the composed frame for the
+ * guesses that follow a passing one (setData at :693 is outside the loop, the one at :719 inside). */
+void ora_loop_closure_verify(ora_ctx* c, const ora_frame* current, const double pose_prior[16], const double* inits,
+                             uint32_t n_init, const float pose_new[16], float conf_threshold, float min_valid_ratio,
+                             float max_outlier_ratio, ora_loop_result* out) {
+  float prior_f[16];
+  o_cast(pose_prior, prior_f);
+  ora_map_render_inactive(c, prior_f, conf_threshold); /* :679 */
+  const ora_frame* model = ora_map_frame(c, SUMA_FRAME_OLD); /* :693 */
+  for (uint32_t k = 0; k < n_init; ++k) {
+    ora_loop_result* o = &out[k];
+    memset(o, 0, sizeof(*o));
+    suma_icp_stats mst;
+    ora_icp_minimize(c, current, model, inits + 16 * (size_t)k, o->gn_pose, NULL, 0, NULL, &mst); /* :700 */
+    const uint32_t iteration = mst.iterations + (mst.converged ? 1u : 0u); /* Frame2Model::iteration_ keeps counting */
+    ora_icp_jacobian_products(c, current, model, o->gn_pose, iteration, NULL, NULL, NULL, &o->after_minimize); /* :705 */
+    o->after_minimize.iterations = mst.iterations;
+    o->after_minimize.converged = mst.converged;
+    const suma_icp_stats* s0 = &o->after_minimize;
+    const float valid_ratio = (float)s0->valid / (float)(s0->valid + s0->invalid);       /* :707 */
+    const float outlier_ratio = (float)s0->outlier / (float)(s0->outlier + s0->inlier); /* :708 */
+    double pd[16];
+    o_mul4(pose_prior, o->gn_pose, pd);
+    o_cast(pd, o->pose_old); /* :714 */
+    o->passed = (valid_ratio > min_valid_ratio && outlier_ratio < max_outlier_ratio) ? 1 : 0; /* :713 */
+    if (o->passed) {
+      ora_map_render_composed(c, o->pose_old, pose_new, conf_threshold); /* :717 */
+      model = ora_map_frame(c, SUMA_FRAME_COMPOSED);                     /* :719 */
+      double I[16];
+      o_eye(I);
+      ora_icp_jacobian_products(c, current, model, I, 0, NULL, o->JtJ, NULL, &o->composed); /* :720-723 */
+    }
+  }
+}
+
+/* checkLoopClosure, part 1 (SurfelMapping.cpp:546-574): a tracked closure is verified again on the next scans */
+void ora_loop_closure_track(ora_ctx* c, const ora_frame* current, const double last_pose_old[16],
+                            const double last_increment[16], const float pose_new[16], float conf_threshold,
+                            double min_valid_ratio, double max_outlier_ratio, double max_increment_difference,
+                            ora_loop_track* o) {
+  memset(o, 0, sizeof(*o));
+  float pf[16];
+  o_cast(last_pose_old, pf);                      /* :548 */
+  ora_map_render_inactive(c, pf, conf_threshold); /* :550 */
+  const ora_frame* model = ora_map_frame(c, SUMA_FRAME_OLD);
+  ora_icp_minimize(c, current, model, last_increment, o->increment_old, NULL, 0, NULL, &o->after_minimize); /* :553-554 */
+  const suma_icp_stats* s0 = &o->after_minimize;
+  const float valid_ratio = (float)s0->valid / (float)(s0->valid + s0->invalid);       /* :557 */
+  const float outlier_ratio = (float)s0->outlier / (float)(s0->outlier + s0->inlier); /* :558 */
+  double la[6], lb[6], sq = 0.0;
+  ora_se3_log(last_increment, la);
+  ora_se3_log(o->increment_old, lb);
+  for (int i = 0; i < 6; ++i) sq += (la[i] - lb[i]) * (la[i] - lb[i]);
+  o->increment_difference = (float)sqrt(sq); /* :561 */
+  o_mul4(last_pose_old, o->increment_old, o->pose_old);
+  o->passed = ((double)valid_ratio > min_valid_ratio && (double)outlier_ratio < max_outlier_ratio &&
+               (double)o->increment_difference < max_increment_difference) ? 1 : 0; /* :563 */
+  if (o->passed) {
+    float po[16];
+    o_cast(o->pose_old, po);                                      /* :564 */
+    ora_map_render_composed(c, po, pose_new, conf_threshold);    /* :567 */
+    double I[16];
+    o_eye(I);
+    ora_icp_jacobian_products(c, current, ora_map_frame(c, SUMA_FRAME_COMPOSED), I, 0, NULL, o->JtJ, NULL, &o->composed); /* :569-572 */
+  }
+}
+
+void ora_pipeline_verify_loop_closure(ora_pipeline* s, const double pose_prior[16], const double* inits, uint32_t n_init,
+                                      float min_valid_ratio, float max_outlier_ratio, ora_loop_result* out) {
+  float pn[16];
+  o_cast(s->pose_new, pn); /* currentPose_new_.cast<float>(), :717 */
+  ora_loop_closure_verify(s->c, s->current_frame, pose_prior, inits, n_init, pn, o_conf_threshold(s), min_valid_ratio,
+                          max_outlier_ratio, out);
+}
+void ora_pipeline_track_loop_closure(ora_pipeline* s, double min_valid_ratio, double max_outlier_ratio,
+                                     double max_increment_difference, ora_loop_track* out) {
+  float pn[16];
+  o_cast(s->pose_new, pn);
+  ora_loop_closure_track(s->c, s->current_frame, s->last_pose_old, s->last_increment, pn, o_conf_threshold(s),
+                         min_valid_ratio, max_outlier_ratio, max_increment_difference, out); /* :563: 0.2, 0.85, 0.1 */
 }

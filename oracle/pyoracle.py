@@ -18,6 +18,18 @@ from semantic_suma_amd.types import ACC_WORDS, SURFEL_DTYPE, IcpStats, SumaParam
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIBS = {}
 
+class OraLoopResult(C.Structure):
+    """ora_loop_result (oracle/suma_oracle.h)"""
+    _fields_ = [("gn_pose", C.c_double * 16), ("after_minimize", IcpStats), ("passed", C.c_int32),
+                ("pose_old", C.c_float * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
+
+
+class OraLoopTrack(C.Structure):
+    """ora_loop_track (oracle/suma_oracle.h)"""
+    _fields_ = [("increment_old", C.c_double * 16), ("after_minimize", IcpStats), ("increment_difference", C.c_float),
+                ("passed", C.c_int32), ("pose_old", C.c_double * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
+
+
 c_f4p = C.POINTER(C.c_float)
 c_f8p = C.POINTER(C.c_double)
 
@@ -114,6 +126,19 @@ def lib(variant: str = ""):
     L.ora_pipeline_frame.restype = vp
     L.ora_pipeline_frame.argtypes = [vp, C.c_int]
     L.ora_se3_exp.argtypes = [vp, vp]
+    L.ora_se3_log.argtypes = [vp, vp]
+    L.ora_pipeline_begin_scan.argtypes = [vp, vp, vp, vp, C.c_uint32]
+    L.ora_pipeline_update_pose.argtypes = [vp, C.c_int32]
+    L.ora_pipeline_update_map.argtypes = [vp]
+    L.ora_pipeline_integrate_loop_closures.argtypes = [vp, vp, C.c_uint32, vp]
+    L.ora_pipeline_set_pose_old.argtypes = [vp, vp]
+    L.ora_pipeline_get_pose.argtypes = [vp, C.c_int, vp]
+    L.ora_pipeline_verify_loop_closure.argtypes = [vp, vp, vp, C.c_uint32, C.c_float, C.c_float, C.POINTER(OraLoopResult)]
+    L.ora_pipeline_track_loop_closure.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.POINTER(OraLoopTrack)]
+    L.ora_loop_closure_verify.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(OraLoopResult)]
+    L.ora_loop_closure_track.argtypes = [vp, vp, vp, vp, vp, C.c_float, C.c_double, C.c_double, C.c_double,
+                                         C.POINTER(OraLoopTrack)]
     L.ora_solve6.argtypes = [vp, vp, vp]
     _LIBS[variant] = L
     return L
@@ -339,8 +364,29 @@ class Oracle:
         return int(ij[0]), int(ij[1])
 
 
+def _cmT(T, dtype):
+    return np.ascontiguousarray(np.asarray(T, dtype=dtype).reshape(4, 4).T)
+
+
+def _loop_results(res, n):
+    out = []
+    for k in range(n):
+        r = res[k]
+        out.append(dict(gn_pose=np.array(r.gn_pose[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
+                        passed=bool(r.passed), pose_old=np.array(r.pose_old[:], dtype=np.float32).reshape(4, 4).T.copy(),
+                        composed=r.composed.as_dict(), JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy()))
+    return out
+
+
+def _loop_track(r):
+    return dict(increment_old=np.array(r.increment_old[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
+                increment_difference=float(r.increment_difference), passed=bool(r.passed),
+                pose_old=np.array(r.pose_old[:]).reshape(4, 4).T.copy(), composed=r.composed.as_dict(),
+                JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy())
+
+
 class OraclePipeline:
-    """SurfelMapping::processScan (no loop closures)."""
+    """SurfelMapping::processScan: one call, or its phases with the loop-closure hooks between them."""
 
     def __init__(self, params: SumaParams, variant: str = "", threads: int = 1):
         self.L = lib(variant)
@@ -361,6 +407,46 @@ class OraclePipeline:
         probs = np.ascontiguousarray(probs, dtype=np.float32)
         self.L.ora_pipeline_process_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0],
                                          fixed_iterations)
+
+    def begin_scan(self, points, labels, probs):
+        points = np.ascontiguousarray(points, dtype=np.float32)
+        labels = np.ascontiguousarray(labels, dtype=np.float32)
+        probs = np.ascontiguousarray(probs, dtype=np.float32)
+        self.L.ora_pipeline_begin_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0])
+
+    def update_pose(self, fixed_iterations=0):
+        self.L.ora_pipeline_update_pose(self.h, fixed_iterations)
+
+    def update_map(self):
+        self.L.ora_pipeline_update_map(self.h)
+
+    def integrate_loop_closures(self, poses, difference):
+        P = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+        D = _cmT(difference, np.float64)
+        self.L.ora_pipeline_integrate_loop_closures(self.h, _ptr(P), P.shape[0], _ptr(D))
+
+    def set_pose_old(self, pose_old):
+        T = _cmT(pose_old, np.float64)
+        self.L.ora_pipeline_set_pose_old(self.h, _ptr(T))
+
+    def get_pose(self, which):
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.L.ora_pipeline_get_pose(self.h, which, _ptr(T))
+        return T.T.copy()
+
+    def verify_loop_closure(self, pose_prior, initializations, min_valid_ratio=0.2, max_outlier_ratio=0.85):
+        n = len(initializations)
+        res = (OraLoopResult * n)()
+        prior = _cmT(pose_prior, np.float64)
+        inits = np.ascontiguousarray(np.stack([_cmT(T, np.float64) for T in initializations]))
+        self.L.ora_pipeline_verify_loop_closure(self.h, _ptr(prior), _ptr(inits), n, min_valid_ratio, max_outlier_ratio, res)
+        return _loop_results(res, n)
+
+    def track_loop_closure(self, min_valid_ratio=0.2, max_outlier_ratio=0.85, max_increment_difference=0.1):
+        r = OraLoopTrack()
+        self.L.ora_pipeline_track_loop_closure(self.h, min_valid_ratio, max_outlier_ratio, max_increment_difference,
+                                               C.byref(r))
+        return _loop_track(r)
 
     def pose(self):
         T = np.zeros((4, 4), dtype=np.float64)
@@ -392,6 +478,13 @@ def se3_exp(x):
     T = np.zeros((4, 4), dtype=np.float64)
     lib().ora_se3_exp(_ptr(x), _ptr(T))
     return T.T.copy()
+
+
+def se3_log(T):
+    Tc = _cmT(T, np.float64)
+    x = np.zeros(6, dtype=np.float64)
+    lib().ora_se3_log(_ptr(Tc), _ptr(x))
+    return x
 
 
 def solve6(JtJ, Jtr):

@@ -88,7 +88,36 @@ void ora_debug_render_quads(const ora_ctx* c, const float pose[16], float conf_t
                             uint8_t* emitted, float* corners, float* pn);
 void ora_map_submap_origin(const ora_ctx* c, int32_t* ij);
 
-/* SurfelMapping::processScan (src/core/SurfelMapping.cpp:175-210) without loop closures */
+/* results of the two device-side parts of SurfelMapping::checkLoopClosure (field for field the product's
+ * suma_loop_result / suma_loop_track, include/suma_hip.h) */
+typedef struct ora_loop_result {
+  double gn_pose[16];
+  suma_icp_stats after_minimize;
+  int32_t passed;
+  float pose_old[16];
+  suma_icp_stats composed;
+  double JtJ[36];
+} ora_loop_result;
+typedef struct ora_loop_track {
+  double increment_old[16];
+  suma_icp_stats after_minimize;
+  float increment_difference;
+  int32_t passed;
+  double pose_old[16];
+  suma_icp_stats composed;
+  double JtJ[36];
+} ora_loop_track;
+void ora_loop_closure_verify(ora_ctx* c, const ora_frame* current, const double pose_prior[16], const double* inits,
+                             uint32_t n_init, const float pose_new[16], float conf_threshold, float min_valid_ratio,
+                             float max_outlier_ratio, ora_loop_result* out); /* SurfelMapping.cpp:679-757 */
+void ora_loop_closure_track(ora_ctx* c, const ora_frame* current, const double last_pose_old[16],
+                            const double last_increment[16], const float pose_new[16], float conf_threshold,
+                            double min_valid_ratio, double max_outlier_ratio, double max_increment_difference,
+                            ora_loop_track* out); /* SurfelMapping.cpp:546-574 */
+void ora_se3_log(const double T[16], double x[6]); /* lie_algebra.cpp:36-71 */
+
+/* SurfelMapping::processScan (src/core/SurfelMapping.cpp:175-210): one call, or its three phases with the loop-closure
+ * hooks between them */
 typedef struct ora_pipeline ora_pipeline;
 ora_pipeline* ora_pipeline_create(const suma_params* p);
 void ora_pipeline_destroy(ora_pipeline* s);
@@ -96,6 +125,18 @@ ora_ctx* ora_pipeline_ctx(ora_pipeline* s);
 /* fixed_iterations > 0: run exactly that many GN iterations (bench mode) */
 void ora_pipeline_process_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
                                uint32_t n, int32_t fixed_iterations);
+void ora_pipeline_begin_scan(ora_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                             uint32_t n);
+void ora_pipeline_update_pose(ora_pipeline* s, int32_t fixed_iterations);
+void ora_pipeline_update_map(ora_pipeline* s);
+void ora_pipeline_integrate_loop_closures(ora_pipeline* s, const float* poses16, uint32_t n, const double difference[16]);
+void ora_pipeline_set_pose_old(ora_pipeline* s, const double pose_old[16]);
+/* which: 0 currentPose_, 1 currentPose_old_, 2 currentPose_new_, 3 lastPose_old_, 4 lastPose_ */
+void ora_pipeline_get_pose(const ora_pipeline* s, int which, double pose[16]);
+void ora_pipeline_verify_loop_closure(ora_pipeline* s, const double pose_prior[16], const double* inits, uint32_t n_init,
+                                      float min_valid_ratio, float max_outlier_ratio, ora_loop_result* out);
+void ora_pipeline_track_loop_closure(ora_pipeline* s, double min_valid_ratio, double max_outlier_ratio,
+                                     double max_increment_difference, ora_loop_track* out); /* reference: 0.2, 0.85, 0.1 */
 void ora_pipeline_pose(const ora_pipeline* s, double pose[16]);
 void ora_pipeline_last_increment(const ora_pipeline* s, double inc[16]);
 void ora_pipeline_last_stats(const ora_pipeline* s, suma_icp_stats* st);

@@ -41,6 +41,12 @@ class LoopResult(C.Structure):
                 ("pose_old", C.c_float * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
 
 
+class LoopTrack(C.Structure):
+    """suma_loop_track (include/suma_hip.h)"""
+    _fields_ = [("increment_old", C.c_double * 16), ("after_minimize", IcpStats), ("increment_difference", C.c_float),
+                ("passed", C.c_int32), ("pose_old", C.c_double * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
+
+
 class IcpObjective(C.Structure):
     """suma_icp_objective (include/suma_hip.h): the parameters one Frame2Model object owns"""
     _fields_ = [("icp_max_distance", C.c_float), ("icp_max_angle", C.c_float), ("weight_function", C.c_int32),
@@ -126,6 +132,20 @@ def lib():
     L.suma_pipeline_process_scan.argtypes = [vp, vp, vp, vp, u32, i32]
     L.suma_pipeline_process_scan_device.argtypes = [vp, vp, vp, vp, u32, i32]
     L.suma_pipeline_pose.argtypes = [vp, vp]
+    L.suma_pipeline_begin_scan.argtypes = [vp, vp, vp, vp, u32]
+    L.suma_pipeline_begin_scan_device.argtypes = [vp, vp, vp, vp, u32]
+    L.suma_pipeline_begin_prefetched.argtypes = [vp]
+    L.suma_pipeline_update_pose.argtypes = [vp, i32]
+    L.suma_pipeline_update_map.argtypes = [vp]
+    L.suma_pipeline_integrate_loop_closures.argtypes = [vp, vp, u32, vp]
+    L.suma_pipeline_set_pose_old.argtypes = [vp, vp]
+    L.suma_pipeline_get_pose.argtypes = [vp, C.c_int, vp]
+    L.suma_pipeline_result_new.argtypes = [vp, C.POINTER(IcpStats)]
+    L.suma_pipeline_verify_loop_closure.argtypes = [vp, vp, vp, u32, f32, f32, C.POINTER(LoopResult)]
+    L.suma_pipeline_track_loop_closure.argtypes = [vp, C.c_double, C.c_double, C.c_double, C.POINTER(LoopTrack)]
+    L.suma_loop_closure_track.argtypes = [vp, vp, vp, vp, vp, f32, C.c_double, C.c_double, C.c_double, C.POINTER(LoopTrack)]
+    L.suma_se3_log.argtypes = [vp, vp]
+    L.suma_se3_log.restype = None
     L.suma_pipeline_last_increment.argtypes = [vp, vp]
     L.suma_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_pipeline_timestamp.restype = u32
@@ -594,8 +614,46 @@ def loop_closure_verify(ctx: Context, current: Frame, pose_prior, initialization
     return out
 
 
+def _loop_results(res, n):
+    out = []
+    for k in range(n):
+        r = res[k]
+        out.append(dict(gn_pose=np.array(r.gn_pose[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
+                        passed=bool(r.passed), pose_old=np.array(r.pose_old[:], dtype=np.float32).reshape(4, 4).T.copy(),
+                        composed=r.composed.as_dict(), JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy()))
+    return out
+
+
+def _loop_track(r):
+    return dict(increment_old=np.array(r.increment_old[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
+                increment_difference=float(r.increment_difference), passed=bool(r.passed),
+                pose_old=np.array(r.pose_old[:]).reshape(4, 4).T.copy(), composed=r.composed.as_dict(),
+                JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy())
+
+
+def se3_log(T):
+    """SE3::log (lie_algebra.cpp:36-71) as the library computes it on the host"""
+    Tc = _cm(T, np.float64)
+    x = np.zeros(6)
+    lib().suma_se3_log(_ptr(Tc), _ptr(x))
+    return x
+
+
+def loop_closure_track(ctx, current, last_pose_old, last_increment, pose_new, conf_threshold, min_valid_ratio=0.2,
+                       max_outlier_ratio=0.85, max_increment_difference=0.1):
+    """device side of SurfelMapping::checkLoopClosure part 1 (SurfelMapping.cpp:546-574)"""
+    r = LoopTrack()
+    a, b, pn = _cm(last_pose_old, np.float64), _cm(last_increment, np.float64), _cm(pose_new, np.float32)
+    ctx.check(ctx.L.suma_loop_closure_track(ctx.h, current.h, _ptr(a), _ptr(b), _ptr(pn), conf_threshold, min_valid_ratio,
+                                            max_outlier_ratio, max_increment_difference, C.byref(r)),
+              "suma_loop_closure_track")
+    return _loop_track(r)
+
+
 class SurfelMapping:
-    """SurfelMapping::processScan (SurfelMapping.cpp:175-210) without loop closures / pose graph."""
+    """SurfelMapping::processScan (SurfelMapping.cpp:175-210).  processScan* run a scan in one call; beginScan /
+    updatePose / updateMap are its phases for hosts that run loop closures between them (verifyLoopClosure,
+    trackLoopClosure, setPoseOld, integrateLoopClosures).  The candidate search and the pose graph stay with the host."""
 
     def __init__(self, params: SumaParams, device: int = 0):
         self.L = lib()
@@ -634,9 +692,13 @@ class SurfelMapping:
                                                           points.shape[0]), "suma_pipeline_prefetch_scan")
 
     def processPrefetched(self, fixed_iterations: int = 0):
-        self.ctx.check(self.L.suma_pipeline_process_prefetched(self.h, fixed_iterations),
-                       "suma_pipeline_process_prefetched")
-        self._staged.pop(0)
+        try:
+            self.ctx.check(self.L.suma_pipeline_process_prefetched(self.h, fixed_iterations),
+                           "suma_pipeline_process_prefetched")
+        finally:
+            # the C side has consumed (and freed) the oldest slot whether or not the scan succeeded
+            if self._staged:
+                self._staged.pop(0)
 
     def processSequence(self, scans, fixed_iterations: int = 0, on_scan=None):
         """run an iterable of (points, labels, probs) with the upload of scan k+1 overlapping the kernels of scan k
@@ -660,6 +722,70 @@ class SurfelMapping:
             if on_scan is not None:
                 on_scan(k, self)
             k += 1
+
+    # ---- the phases of processScan (SurfelMapping.cpp:175-204)
+    def beginScan(self, points, labels=None, probs=None):
+        points = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 4)
+        labels = None if labels is None else np.ascontiguousarray(labels, dtype=np.float32)
+        probs = None if probs is None else np.ascontiguousarray(probs, dtype=np.float32)
+        self.ctx.check(self.L.suma_pipeline_begin_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs), points.shape[0]),
+                       "suma_pipeline_begin_scan")
+
+    def beginScanDevice(self, d_points: int, d_labels: int, d_probs: int, n: int):
+        self.ctx.check(self.L.suma_pipeline_begin_scan_device(self.h, C.c_void_p(d_points), C.c_void_p(d_labels),
+                                                              C.c_void_p(d_probs), n), "suma_pipeline_begin_scan_device")
+
+    def beginPrefetched(self):
+        try:
+            self.ctx.check(self.L.suma_pipeline_begin_prefetched(self.h), "suma_pipeline_begin_prefetched")
+        finally:
+            if self._staged:
+                self._staged.pop(0)
+
+    def updatePose(self, fixed_iterations: int = 0):
+        self.ctx.check(self.L.suma_pipeline_update_pose(self.h, fixed_iterations), "suma_pipeline_update_pose")
+
+    def updateMap(self):
+        self.ctx.check(self.L.suma_pipeline_update_map(self.h), "suma_pipeline_update_map")
+
+    def integrateLoopClosures(self, poses, difference):
+        """poses: n x 4 x 4 (row-major numpy) optimised poses -> map_->updatePoses; difference: 4 x 4 double"""
+        P = np.ascontiguousarray(np.asarray(poses, dtype=np.float32).reshape(-1, 4, 4).transpose(0, 2, 1))
+        D = _cm(difference, np.float64)
+        self.ctx.check(self.L.suma_pipeline_integrate_loop_closures(self.h, _ptr(P), P.shape[0], _ptr(D)),
+                       "suma_pipeline_integrate_loop_closures")
+
+    def setPoseOld(self, pose_old):
+        T = _cm(pose_old, np.float64)
+        self.ctx.check(self.L.suma_pipeline_set_pose_old(self.h, _ptr(T)), "suma_pipeline_set_pose_old")
+
+    def getPose(self, which: int):
+        """0 currentPose_, 1 currentPose_old_, 2 currentPose_new_, 3 lastPose_old_, 4 lastPose_"""
+        T = np.zeros((4, 4), dtype=np.float64)
+        self.ctx.check(self.L.suma_pipeline_get_pose(self.h, which, _ptr(T)), "suma_pipeline_get_pose")
+        return T.T.copy()
+
+    def resultNew(self) -> IcpStats:
+        st = IcpStats()
+        self.ctx.check(self.L.suma_pipeline_result_new(self.h, C.byref(st)), "suma_pipeline_result_new")
+        return st
+
+    def verifyLoopClosure(self, pose_prior, initializations, min_valid_ratio=0.2, max_outlier_ratio=0.85):
+        n = len(initializations)
+        res = (LoopResult * n)()
+        prior = _cm(pose_prior, np.float64)
+        inits = np.ascontiguousarray(np.stack([_cm(T, np.float64) for T in initializations]))
+        self.ctx.check(self.L.suma_pipeline_verify_loop_closure(self.h, _ptr(prior), _ptr(inits), n, min_valid_ratio,
+                                                                max_outlier_ratio, res),
+                       "suma_pipeline_verify_loop_closure")
+        return _loop_results(res, n)
+
+    def trackLoopClosure(self, min_valid_ratio=0.2, max_outlier_ratio=0.85, max_increment_difference=0.1):
+        r = LoopTrack()
+        self.ctx.check(self.L.suma_pipeline_track_loop_closure(self.h, min_valid_ratio, max_outlier_ratio,
+                                                               max_increment_difference, C.byref(r)),
+                       "suma_pipeline_track_loop_closure")
+        return _loop_track(r)
 
     def getCurrentPose(self):
         T = np.zeros((4, 4), dtype=np.float64)

@@ -492,6 +492,10 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       /* ---- LieGaussNewton::step on wave 0: every lane runs it on wave-uniform values (same cost as one
        *      lane), the 6x6 solve spreads its rows over lanes 0..5, lane 0 writes ---- */
       const int lane = threadIdx.x;
+      /* s_wave / s_val were written by OTHER lanes of this wave: a wavefront-scope fence + wave barrier pins the
+       * order for the compiler (the hardware executes one wave's LDS traffic in order; no instruction is emitted) */
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       const double err = s_val[27];
       if (writer) {
         gout->F = err;
@@ -562,6 +566,8 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         gout->converged = converged;
         gout->done = done;
       }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); /* lane 0's s_E stores before the other lanes' loads */
+      __builtin_amdgcn_wave_barrier();
       if (lane < 16) {
         /* pose_ = SE3::exp(delta) * pose_ -- applied even when converged (Objective.h:46): one element per
          * lane, the expression of mul4d().  LDS traffic of one wave is in order: lane 0's s_E stores above
@@ -662,13 +668,20 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   fix_consts(&fx_scale, &fx_magic);
 
   const float fWm = (float)a.Wm, fHm = (float)a.Hm;
-  for (uint32_t pix = pix0; pix < a.P; pix += gridDim.x * ICP_THREADS) {
+  /* The trip count is WAVE-uniform (the wave's first pixel decides): wave_reduce16 exchanges words between all 64
+   * lanes, so a lane whose pixel lies beyond the image (P not a multiple of 64) must stay in the loop and hand in
+   * zeros instead of leaving it. */
+  for (uint32_t pix = pix0; pix - (threadIdx.x & 63u) < a.P; pix += gridDim.x * ICP_THREADS) {
+    const bool valid_px = pix < a.P; /* this lane's trip processes a pixel of the image */
     if (pix != pix0) {
-      vd4 = a.Vd[pix];
-      nd4 = a.Nd[pix];
-      sd4 = a.Sd[pix];
+      vd4 = nd4 = sd4 = f4(0, 0, 0, 0);
+      if (valid_px) {
+        vd4 = a.Vd[pix];
+        nd4 = a.Nd[pix];
+        sd4 = a.Sd[pix];
+      }
     }
-    if (a.k8_enabled) { /* launch-uniform */
+    if (a.k8_enabled && valid_px) { /* k8_enabled is launch-uniform */
       k8_pixel(a.k8, pix, vd4, nd4, sd4);
       if (pix == 0) {
         a.k8_ds->n_updated = 0;
@@ -710,7 +723,6 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     }
     float J[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, wgt = 0.f, wr = 0.f, wr2 = 0.f;
     bool is_inlier = false;
-    const bool valid_px = true; /* this trip processes a pixel of the image (the loop bound guarantees it) */
     if (pair) {
       v3 v_m = xyz(vm4), n_m = xyz(nm4);
       bool inlier = true;

@@ -407,6 +407,9 @@ extern "C" int suma_set_params(suma_ctx* c, const suma_params* p) {
   c->p.cache_surfels = cache;
   derive(c);
   c->params_version++;
+  /* a Frame2Model object's own values (suma_icp_set_objective) do not outlive a new parameter block: whoever sends
+   * parameters expects the next launch to use them; the adapter objects re-send theirs before every launch anyway */
+  c->obj_set = false;
   return SUMA_OK;
 }
 extern "C" int suma_synchronize(suma_ctx* c) {
@@ -1048,6 +1051,81 @@ extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, 
   return SUMA_OK;
 }
 
+/* SE3::log, lie_algebra.cpp:36-71 (host side, double, libm) */
+extern "C" void suma_se3_log(const double T[16], double x[6]) {
+  /* column-major: R(r, c) = T[4 * c + r] */
+  const double d = 0.5 * (((T[0] + T[5]) + T[10]) - 1.0);
+  double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; /* omega_skew, row-major W[3 * r + c] */
+  for (int i = 0; i < 6; ++i) x[i] = 0.0;
+  if (d < 1 - 1e-10) {
+    const double theta = acos(d);
+    const double f = theta / (2 * sin(theta));
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) W[3 * r + cc] = f * (T[4 * cc + r] - T[4 * r + cc]);
+    x[3] = W[3 * 2 + 1];
+    x[4] = W[3 * 0 + 2];
+    x[5] = W[3 * 1 + 0];
+  }
+  const double theta = sqrt((x[3] * x[3] + x[4] * x[4]) + x[5] * x[5]);
+  const double t[3] = {T[12], T[13], T[14]};
+  x[0] = t[0];
+  x[1] = t[1];
+  x[2] = t[2];
+  if (fabs(theta) > 1e-10) {
+    const double half_theta = 0.5 * theta;
+    const double alpha = -0.5;
+    const double beta = 1 / (theta * theta) * (1 - theta * cos(half_theta) / (2 * sin(half_theta)));
+    double W2[9], Vi[9];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc)
+        W2[3 * r + cc] = (W[3 * r] * W[cc] + W[3 * r + 1] * W[3 + cc]) + W[3 * r + 2] * W[6 + cc];
+    for (int r = 0; r < 3; ++r)
+      for (int cc = 0; cc < 3; ++cc) Vi[3 * r + cc] = ((r == cc ? 1.0 : 0.0) + alpha * W[3 * r + cc]) + beta * W2[3 * r + cc];
+    for (int r = 0; r < 3; ++r) x[r] = (Vi[3 * r] * t[0] + Vi[3 * r + 1] * t[1]) + Vi[3 * r + 2] * t[2];
+  }
+}
+
+/* checkLoopClosure, part 1 (SurfelMapping.cpp:546-574): a closure that is being tracked is verified again */
+extern "C" int suma_loop_closure_track(suma_ctx* c, const suma_frame* current, const double last_pose_old[16],
+                                       const double last_increment[16], const float pose_new[16], float conf_threshold,
+                                       double min_valid_ratio, double max_outlier_ratio, double max_increment_difference,
+                                       suma_loop_track* o) {
+  if (!c || !current || !last_pose_old || !last_increment || !pose_new || !o) return SUMA_ERR_INVALID;
+  memset(o, 0, sizeof(*o));
+  float pf[16];
+  for (int i = 0; i < 16; ++i) pf[i] = (float)last_pose_old[i]; /* :548 */
+  int r = suma_map_render_inactive(c, pf, conf_threshold); /* :550 */
+  if (r) return r;
+  r = suma_icp_set_data(c, current, c->old_frame); /* :553 */
+  if (r) return r;
+  r = suma_icp_minimize(c, last_increment, o->increment_old, nullptr, 0, nullptr, &o->after_minimize); /* :554 */
+  if (r) return r;
+  const suma_icp_stats& s0 = o->after_minimize; /* the objective's counters as the last step left them (:557-558) */
+  const float valid_ratio = (float)s0.valid / (float)(s0.valid + s0.invalid);
+  const float outlier_ratio = (float)s0.outlier / (float)(s0.outlier + s0.inlier);
+  double la[6], lb[6], sq = 0.0;
+  suma_se3_log(last_increment, la);
+  suma_se3_log(o->increment_old, lb);
+  for (int i = 0; i < 6; ++i) sq += (la[i] - lb[i]) * (la[i] - lb[i]);
+  o->increment_difference = (float)sqrt(sq); /* :561 */
+  mul4_dd(last_pose_old, o->increment_old, o->pose_old);
+  o->passed = ((double)valid_ratio > min_valid_ratio && (double)outlier_ratio < max_outlier_ratio &&
+               (double)o->increment_difference < max_increment_difference) ? 1 : 0; /* :563: floats against double literals */
+  if (o->passed) {
+    float po[16];
+    for (int i = 0; i < 16; ++i) po[i] = (float)o->pose_old[i]; /* :564 */
+    r = suma_map_render_composed(c, po, pose_new, conf_threshold); /* :567 */
+    if (r) return r;
+    r = suma_icp_set_data(c, current, c->composed_frame); /* :569 */
+    if (r) return r;
+    double I[16];
+    for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    r = suma_icp_jacobian_products(c, I, 0, o->JtJ, nullptr, nullptr, &o->composed); /* :570-572 */
+    if (r) return r;
+  }
+  return SUMA_OK;
+}
+
 /* ---------------------------------------------------------------------------------------------
  * SurfelMapping::processScan
  * ------------------------------------------------------------------------------------------- */
@@ -1123,6 +1201,8 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
   eye_d(s->pose_old);
   eye_d(s->pose_new);
   eye_d(s->last_increment);
+  eye_d(s->last_pose_old);
+  s->phase = 0;
   float p_unstable = 0.1f; /* SurfelMapping.cpp:108-109 */
   s->log_unstable = (float)log((double)(p_unstable / (1.0f - p_unstable)));
   *out = s;
@@ -1330,17 +1410,21 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
   double np[16];
   mul4_d(s->current_pose, increment, np);
   memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->last_pose_old, s->pose_old, sizeof(s->last_pose_old)); /* :456 */
   memcpy(s->pose_old, np, sizeof(np));
   memcpy(s->pose_new, np, sizeof(np));
   memcpy(s->last_increment, increment, sizeof(increment));
   return SUMA_OK;
 }
 
-/* upload_done: optional event on another stream that the scan's device buffers depend on (device-side ingest) */
-int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                               const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done) {
+/* ---- the three phases of SurfelMapping::processScan (SurfelMapping.cpp:175-204) ----
+ * upload_done: optional event on another stream that the scan's device buffers depend on (device-side ingest) */
+int pipeline_begin_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
+                             uint32_t n, hipEvent_t upload_done) {
   if (!s || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
   suma_ctx* c = s->c;
+  if (s->phase != 0) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_begin_scan: the previous scan has not been closed with suma_pipeline_update_map");
+  c->obj_set = false; /* the pipeline's objective_ runs on the ctx parameters (suma_params), not on a stale adapter object's */
   /* initialize(), SurfelMapping.cpp:323-331 */
   std::swap(s->last_frame, s->current_frame);
   std::swap(s->last_model, s->current_model);
@@ -1369,19 +1453,103 @@ int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, co
   cast_f(s->pose_new, pn);
   r = map_render_dedup(c, po, pn, conf_threshold(s), s->last_model);
   if (r) return r;
-  if (s->timestamp > 0) {
-    r = update_pose(s, fixed_iterations);
+  s->phase = 1;
+  return SUMA_OK;
+}
+
+int pipeline_update_pose_impl(suma_pipeline* s, int32_t fixed_iterations) {
+  if (!s) return SUMA_ERR_INVALID;
+  if (s->phase != 1) return fail(s->c, SUMA_ERR_INVALID, "suma_pipeline_update_pose: call suma_pipeline_begin_scan first");
+  if (s->timestamp > 0) { /* :190 */
+    int r = update_pose(s, fixed_iterations);
     if (r) return r;
   }
-  /* updateMap(), :797-804 */
+  s->phase = 2;
+  return SUMA_OK;
+}
+
+/* updateMap(), :797-804, and timestamp_ += 1 (:209) */
+int pipeline_update_map_impl(suma_pipeline* s) {
+  if (!s) return SUMA_ERR_INVALID;
+  suma_ctx* c = s->c;
+  if (s->phase != 2) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_update_map: call suma_pipeline_update_pose first");
   float pc[16];
   cast_f(s->current_pose, pc);
-  r = suma_map_update(c, pc, s->current_frame);
+  int r = suma_map_update(c, pc, s->current_frame);
   if (r) return r;
   r = map_render_dedup(c, pc, pc, conf_threshold(s), s->current_model);
   if (r) return r;
   s->timestamp += 1;
+  s->phase = 0;
   return SUMA_OK;
+}
+
+hipStream_t pipeline_input_stream(suma_pipeline* s) { return s->c->side_stream ? s->c->side_stream : s->c->stream; }
+
+int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                               const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done) {
+  int r = pipeline_begin_scan_impl(s, d_points, d_labels, d_probs, n, upload_done);
+  if (r == SUMA_OK) r = pipeline_update_pose_impl(s, fixed_iterations);
+  if (r == SUMA_OK) r = pipeline_update_map_impl(s);
+  if (r != SUMA_OK && s) s->phase = 0; /* a failed scan does not wedge the phase check */
+  return r;
+}
+
+extern "C" int suma_pipeline_begin_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                                               const float* d_probs, uint32_t n) {
+  return pipeline_begin_scan_impl(s, d_points, d_labels, d_probs, n, nullptr);
+}
+extern "C" int suma_pipeline_update_pose(suma_pipeline* s, int32_t fixed_iterations) {
+  return pipeline_update_pose_impl(s, fixed_iterations);
+}
+extern "C" int suma_pipeline_update_map(suma_pipeline* s) { return pipeline_update_map_impl(s); }
+
+/* integrateLoopClosures, SurfelMapping.cpp:211-250 (the part behind the optimiser's future) */
+extern "C" int suma_pipeline_integrate_loop_closures(suma_pipeline* s, const float* poses16, uint32_t n,
+                                                     const double difference[16]) {
+  if (!s || !difference || (!poses16 && n)) return SUMA_ERR_INVALID;
+  suma_ctx* c = s->c;
+  if (s->phase != 0) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_integrate_loop_closures: only between scans (SurfelMapping.cpp:179)");
+  int r = suma_map_update_poses(c, poses16, n); /* :236 */
+  if (r) return r;
+  double np[16];
+  mul4_d(difference, s->current_pose, np); /* :239 */
+  memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->pose_old, np, sizeof(np)); /* :243 */
+  memcpy(s->pose_new, np, sizeof(np));
+  return SUMA_OK;
+}
+extern "C" int suma_pipeline_set_pose_old(suma_pipeline* s, const double pose_old[16]) {
+  if (!s || !pose_old) return SUMA_ERR_INVALID;
+  memcpy(s->pose_old, pose_old, sizeof(s->pose_old));
+  return SUMA_OK;
+}
+extern "C" int suma_pipeline_get_pose(const suma_pipeline* s, int which, double pose[16]) {
+  if (!s || !pose || which < 0 || which > 4) return SUMA_ERR_INVALID;
+  const double* src[5] = {s->current_pose, s->pose_old, s->pose_new, s->last_pose_old, s->last_pose};
+  memcpy(pose, src[which], 16 * sizeof(double));
+  return SUMA_OK;
+}
+extern "C" int suma_pipeline_result_new(suma_pipeline* s, suma_icp_stats* st) { return suma_pipeline_last_stats(s, st); }
+
+extern "C" int suma_pipeline_verify_loop_closure(suma_pipeline* s, const double pose_prior[16],
+                                                 const double* initializations, uint32_t n_init, float min_valid_ratio,
+                                                 float max_outlier_ratio, suma_loop_result* out) {
+  if (!s) return SUMA_ERR_INVALID;
+  if (s->phase != 2) return fail(s->c, SUMA_ERR_INVALID, "suma_pipeline_verify_loop_closure: between suma_pipeline_update_pose and suma_pipeline_update_map (SurfelMapping.cpp:196)");
+  float pn[16];
+  cast_f(s->pose_new, pn); /* currentPose_new_.cast<float>(), :717 */
+  return suma_loop_closure_verify(s->c, s->current_frame, pose_prior, initializations, n_init, pn, conf_threshold(s),
+                                  min_valid_ratio, max_outlier_ratio, out);
+}
+extern "C" int suma_pipeline_track_loop_closure(suma_pipeline* s, double min_valid_ratio, double max_outlier_ratio,
+                                                double max_increment_difference, suma_loop_track* out) {
+  if (!s) return SUMA_ERR_INVALID;
+  if (s->phase != 2) return fail(s->c, SUMA_ERR_INVALID, "suma_pipeline_track_loop_closure: between suma_pipeline_update_pose and suma_pipeline_update_map (SurfelMapping.cpp:196)");
+  float pn[16];
+  cast_f(s->pose_new, pn);
+  return suma_loop_closure_track(s->c, s->current_frame, s->last_pose_old, s->last_increment, pn, conf_threshold(s),
+                                 min_valid_ratio, max_outlier_ratio, max_increment_difference, out);
 }
 
 extern "C" int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,

@@ -300,7 +300,8 @@ extern "C" int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* 
   return SUMA_OK;
 }
 
-extern "C" int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_iterations) {
+/* the oldest staged scan: begin (phases_only) or the whole scan */
+static int run_prefetched(suma_pipeline* s, int32_t fixed_iterations, bool begin_only) {
   if (!s || !s->ingest) return SUMA_ERR_INVALID;
   Ingest* g = s->ingest;
   suma_ctx* c = s->c;
@@ -321,20 +322,31 @@ extern "C" int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_
     }
   }
   const uint32_t n = q->n;
+  const suma_float4* dp = (const suma_float4*)q->device;
+  const float* dl = q->labels ? (const float*)(q->device + labels_offset(n)) : nullptr;
+  const float* dq = q->probs ? (const float*)(q->device + probs_offset(n)) : nullptr;
   /* the stream that runs the scan's preprocessing waits for the upload (device-side dependency) */
-  int r = pipeline_process_scan_impl(s, (const suma_float4*)q->device,
-                                     q->labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
-                                     q->probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n,
-                                     fixed_iterations, q->uploaded);
-  const hipError_t ec = hipEventRecord(q->consumed, c->stream);
+  int r = pipeline_begin_scan_impl(s, dp, dl, dq, n, q->uploaded);
+  /* the slot is free again once the preprocessing that read its device block has run: recorded on the stream that
+   * carries it (the side stream, where an event record costs the scan nothing) */
+  const hipError_t ec = hipEventRecord(q->consumed, pipeline_input_stream(s));
   {
     std::lock_guard<std::mutex> lk(g->mu);
     q->consumed_valid = (ec == hipSuccess);
     q->state = 0;
     g->head += 1;
   }
+  if (r == SUMA_OK && !begin_only) {
+    r = pipeline_update_pose_impl(s, fixed_iterations);
+    if (r == SUMA_OK) r = pipeline_update_map_impl(s);
+  }
+  if (r != SUMA_OK) s->phase = 0;
   return r;
 }
+extern "C" int suma_pipeline_process_prefetched(suma_pipeline* s, int32_t fixed_iterations) {
+  return run_prefetched(s, fixed_iterations, false);
+}
+extern "C" int suma_pipeline_begin_prefetched(suma_pipeline* s) { return run_prefetched(s, 0, true); }
 
 extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_float4* points, const float* labels,
                                                 const float* probs, uint32_t n, int32_t fixed_iterations) {
@@ -363,8 +375,8 @@ extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_flo
  * the scan is copied into pinned memory by the caller and COPY_HELPERS helper threads, uploaded on the copy stream, and
  * the preprocessing waits for the upload on the device -- the call returns as early as the device-pointer entry does,
  * so the surfel passes of this scan overlap the next call's copy. */
-int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
-                               uint32_t n, int32_t fixed_iterations) {
+static int run_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                         int32_t fixed_iterations, bool begin_only) {
   Ingest* g = nullptr;
   int r = ingest_get(s, &g);
   if (r) return r;
@@ -396,8 +408,23 @@ int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, cons
     HIP_TRY(c, hipMemcpyAsync(q->device, q->pinned, bytes, hipMemcpyHostToDevice, g->copy_stream));
   }
   HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
-  r = pipeline_process_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
-                                 probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, fixed_iterations, q->uploaded);
-  q->consumed_valid = (hipEventRecord(q->consumed, c->stream) == hipSuccess);
+  r = pipeline_begin_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
+                               probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, q->uploaded);
+  q->consumed_valid = (hipEventRecord(q->consumed, pipeline_input_stream(s)) == hipSuccess);
+  if (r == SUMA_OK && !begin_only) {
+    r = pipeline_update_pose_impl(s, fixed_iterations);
+    if (r == SUMA_OK) r = pipeline_update_map_impl(s);
+  }
+  if (r != SUMA_OK) s->phase = 0;
   return r;
+}
+int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
+                               uint32_t n, int32_t fixed_iterations) {
+  return run_host_scan(s, points, labels, probs, n, fixed_iterations, false);
+}
+/* initialize + preprocess of SurfelMapping::processScan with the host vectors the reference's caller holds */
+extern "C" int suma_pipeline_begin_scan(suma_pipeline* s, const suma_float4* points, const float* labels,
+                                        const float* probs, uint32_t n) {
+  if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
+  return run_host_scan(s, points, labels, probs, n, 0, true);
 }

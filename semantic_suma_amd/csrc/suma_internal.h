@@ -214,7 +214,9 @@ struct suma_pipeline {
   suma_ctx* c;
   suma_frame *last_frame, *current_frame, *current_model, *last_model;
   double current_pose[16], last_pose[16], pose_old[16], pose_new[16], last_increment[16];
+  double last_pose_old[16]; /* lastPose_old_, SurfelMapping.cpp:456 */
   uint32_t timestamp;
+  int phase; /* 0: between scans, 1: begin_scan done, 2: update_pose done (suma_pipeline_begin_scan / _update_pose / _update_map) */
   float log_unstable;
   suma_icp_stats stats;
   uint32_t track_loss;
@@ -230,6 +232,12 @@ struct suma_pipeline {
 
 int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
                                uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done);
+int pipeline_begin_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
+                             uint32_t n, hipEvent_t upload_done);
+int pipeline_update_pose_impl(suma_pipeline* s, int32_t fixed_iterations);
+int pipeline_update_map_impl(suma_pipeline* s);
+/* the stream behind which a scan's input buffers are free again (the preprocessing that read them runs there) */
+hipStream_t pipeline_input_stream(suma_pipeline* s);
 /* suma_ingest.hip */
 void ingest_destroy(suma_pipeline* s);
 int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,

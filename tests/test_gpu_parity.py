@@ -594,8 +594,10 @@ def test_pipeline_model_image_differs_from_data_image(hip, oracle_lib):
 
 
 def test_tiny_and_odd_image_sizes(hip, oracle_lib):
-    """16 beams x 180 columns and a width that is not a multiple of any tile size"""
-    for (w, h) in ((180, 16), (1000, 40)):
+    """16 beams x 180 columns, a width that is not a multiple of any tile size, and two images whose pixel count is
+    not a multiple of the 64-lane wave (450 x 16 = 112.5 waves, 333 x 10): the wave reductions of K6 must not lose the
+    lanes beyond the image (round-2 advisor finding)"""
+    for (w, h) in ((180, 16), (1000, 40), (450, 16), (333, 10)):
         p = params_with_size(w, h)
         hp = hip.SurfelMapping(p)
         op = oracle_lib.OraclePipeline(p)
@@ -604,6 +606,7 @@ def test_tiny_and_odd_image_sizes(hip, oracle_lib):
             hp.processScan(pts, lab, prob, fixed_iterations=6)
             op.process_scan(pts, lab, prob, fixed_iterations=6)
             assert np.array_equal(hp.getCurrentPose(), op.pose()), f"{w}x{h} scan {k} pose"
+            assert hp.lastStats().as_dict() == op.last_stats().as_dict(), f"{w}x{h} scan {k} stats"
             assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"{w}x{h} scan {k} surfels"
             for f in (0, 2):
                 frames_equal(hp.frame(f), op.frame(f), f"{w}x{h} scan {k} frame {f}")
