@@ -48,6 +48,10 @@ struct RenderArgs {
   int use_stability;
   int32_t thr;
   RenderSlot slot[2];
+  /* both slots look from the SAME pose with the same tie rule (render() without loop closing: pose_old == pose_new
+   * bit for bit): one trip per tile serves both -- transform, gating and the quad of a surfel are computed once, a
+   * 2-bit mask per record says which z-buffers its fragments go to */
+  int merged;
   /* optional K7 (gen_indexmap.vert:62-81) fused into this pass: the index-map splat of the same
    * surfels from slot[0]'s pose into the data-sized z-buffer */
   const float* inv_pose_dev; /* if set: slot 0 (and the fused K7) take the inverse pose from HBM */
@@ -182,7 +186,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
   __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
   __shared__ int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
   __shared__ uint32_t s_incl[RENDER_THREADS];
-  __shared__ uint32_t s_w[2][RENDER_WAVES];
+  __shared__ uint32_t s_w[2][RENDER_WAVES], s_w2[RENDER_WAVES];
+  __shared__ uint8_t s_mask[RENDER_THREADS]; /* slot mask of a candidate, by candidate rank */
   const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -191,6 +196,8 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
    * head mostly surfels that leave after phase 1a.  Dispatching the expensive tiles first keeps the cheap
    * ones for the kernel's tail. */
   const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
+  const int npass = a.merged ? 1 : 2;
+  uint32_t trip = 0; /* counts rank barriers: the per-wave counters alternate between two sets (see the early-out) */
   PH_BEGIN;
   for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     PH(7); /* loop overhead / previous tile's tail */
@@ -211,13 +218,21 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
     if (live && ts == 0x7fffffff) ph_acc[7] += 1; /* consumes the loads before the stamp */
 #endif
     PH(0); /* surfel loads arrived */
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-      const RenderSlot& slot = a.slot[sl];
-      if (!slot.enabled) continue; /* kernel-uniform */
+    for (int sl = 0; sl < npass; ++sl) {
+      /* merged: one trip, slot[1]'s pose (== slot[0]'s); otherwise one trip per enabled slot */
+      const RenderSlot& slot = a.slot[a.merged ? 1 : sl];
+      if (!a.merged && !slot.enabled) continue; /* kernel-uniform */
       const float* inv_pose = (sl == 0 && a.inv_pose_dev != nullptr) ? a.inv_pose_dev : slot.inv_pose.m;
       /* ---- phase 1a ---- */
-      const bool selected = live && ((slot.mode == 0) ? (creation < a.thr) : (creation >= a.thr || ts >= a.thr));
+      uint32_t selmask; /* bit b: the record renders into slot[b].zbuf */
+      {
+        const bool sel_old = live && (creation < a.thr), sel_new = live && (creation >= a.thr || ts >= a.thr);
+        if (a.merged)
+          selmask = ((sel_old && a.slot[0].enabled) ? 1u : 0u) | (sel_new ? 2u : 0u);
+        else
+          selmask = ((slot.mode == 0) ? sel_old : sel_new) ? (1u << sl) : 0u;
+      }
+      const bool selected = selmask != 0;
       const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
       bool cand = false;
       unsigned long long k7_key = SUMA_EMPTY_KEY;
@@ -248,8 +263,17 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         }
       }
       uint32_t ncand;
-      const uint32_t crank = render_block_rank(cand, s_w[0], &ncand);
+      const uint32_t crank = render_block_rank(cand, s_w[trip & 1u], &ncand);
+      trip += 1;
       PH(1); /* phase 1a + rank barrier */
+      if (ncand == 0) {
+        /* Nothing of this tile renders into this slot (block-uniform: every thread totals the same counters) --
+         * the rule for the "old" slot of render() outside loop closures, and for tiles that are out of view: no
+         * candidate list, no prefix, no closing barrier.  The LDS lists are untouched; the rank counters of the next
+         * trip live in the other set, and that trip's barrier separates this trip's reads from the set's next use. */
+        if (k7_key != SUMA_EMPTY_KEY) zbuf_min(&a.k7_zbuf[k7_pix], k7_key);
+        continue;
+      }
       if (cand) {
         float* r = s_cand[crank];
         r[0] = p.x;
@@ -261,6 +285,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         r[6] = radius;
         r[7] = ppx;
         r[8] = __uint_as_float(i);
+        s_mask[crank] = (uint8_t)selmask;
       }
       __syncthreads();
       PH(2); /* candidate list written + barrier */
@@ -330,6 +355,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
               q[13] = j0;
               q[14] = w;
               q[15] = __float_as_int(r[8]);
+              q[16] = (int32_t)s_mask[threadIdx.x];
             }
           }
         }
@@ -337,12 +363,12 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       PH(3); /* phase 1b */
       /* inclusive prefix of the test counts over the block */
       uint32_t incl = wave_inclusive_scan(ntests);
-      if (lane == 63) s_w[1][wave] = incl;
+      if (lane == 63) s_w2[wave] = incl;
       __syncthreads();
       uint32_t woff = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < RENDER_WAVES; ++w) {
-        uint32_t c = s_w[1][w];
+        uint32_t c = s_w2[w];
         if (w < wave) woff += c;
         total += c;
       }
@@ -358,14 +384,17 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       unsigned long long k7_cur = 0;
       if (k7_key != SUMA_EMPTY_KEY)
         k7_cur = __hip_atomic_load(&a.k7_zbuf[k7_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* const zb0 = a.slot[0].zbuf;
+      unsigned long long* const zb1 = a.slot[1].zbuf;
       for (uint32_t t0 = threadIdx.x; t0 < total; t0 += RENDER_BATCH * RENDER_THREADS) {
         unsigned long long key[RENDER_BATCH];
-        uint32_t pix[RENDER_BATCH];
+        uint32_t pix[RENDER_BATCH], msk[RENDER_BATCH];
 #pragma unroll
         for (int u = 0; u < RENDER_BATCH; ++u) {
           const uint32_t t = t0 + (uint32_t)u * RENDER_THREADS;
           key[u] = SUMA_EMPTY_KEY;
           pix[u] = 0;
+          msk[u] = 0;
           if (t < total) {
             /* source record: the first one whose inclusive prefix exceeds t */
             int lo = 0, hi = RENDER_THREADS - 1;
@@ -398,17 +427,24 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
             const unsigned long long kb = raster_key(vt[2], vt[1], vt[3], pi, pj, id, slot.tie);
             key[u] = ka < kb ? ka : kb;
             pix[u] = (uint32_t)pj * (uint32_t)a.q.W + (uint32_t)pi;
+            msk[u] = (uint32_t)r[16];
           }
         }
-        unsigned long long cur[RENDER_BATCH];
+        /* a z-buffer a fragment does not go to reads as 0: no key is smaller, no atomic follows */
+        unsigned long long cur0[RENDER_BATCH], cur1[RENDER_BATCH];
 #pragma unroll
         for (int u = 0; u < RENDER_BATCH; ++u) {
-          cur[u] = 0;
-          if (key[u] != SUMA_EMPTY_KEY) cur[u] = __hip_atomic_load(&slot.zbuf[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          cur0[u] = cur1[u] = 0;
+          if (key[u] != SUMA_EMPTY_KEY) {
+            if (msk[u] & 1u) cur0[u] = __hip_atomic_load(&zb0[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (msk[u] & 2u) cur1[u] = __hip_atomic_load(&zb1[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
 #pragma unroll
-        for (int u = 0; u < RENDER_BATCH; ++u)
-          if (key[u] < cur[u]) atomicMin(&slot.zbuf[pix[u]], key[u]);
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          if (key[u] < cur0[u]) atomicMin(&zb0[pix[u]], key[u]);
+          if (key[u] < cur1[u]) atomicMin(&zb1[pix[u]], key[u]);
+        }
       }
       if (k7_key < k7_cur) atomicMin(&a.k7_zbuf[k7_pix], k7_key);
       PH(5); /* phase 2: pixel tests, z-buffer reads, atomics */
@@ -529,6 +565,9 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.use_stability = c->p.use_stability;
   a.thr = thr;
   a.slot[0].enabled = a.slot[1].enabled = 0;
+  a.slot[0].zbuf = a.slot[1].zbuf = c->zbuf_a; /* valid addresses even for a slot that stays off */
+  a.slot[0].tie = a.slot[1].tie = TIE_LOW_INDEX;
+  a.merged = 0;
   a.inv_pose_dev = nullptr;
   a.k7_enabled = 0;
   a.k7_q = c->pd;
@@ -583,6 +622,8 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     a.slot[1].tie = TIE_LOW_INDEX;
     a.slot[1].zbuf = c->zbuf_b;
     set_m4(a.slot[1].inv_pose, inv_new);
+    /* outside loop closures currentPose_old_ == currentPose_new_ (SurfelMapping.cpp:457-458): one trip per tile */
+    a.merged = (memcmp(inv_old, inv_new, sizeof(inv_old)) == 0 && !getenv("SUMA_RENDER_NO_MERGE")) ? 1 : 0;
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
       k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);

@@ -92,7 +92,7 @@ def test_bench_contract_with_two_ranks_on_one_device():
     env = dict(os.environ, SUMA_BENCH_FORCE_DEVICE="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6",
-           "--warmup", "2", "--backend", "gloo", "--cpu-scans", "0", "--no-kernel-events"]
+           "--warmup", "2", "--backend", "gloo", "--cpu-scans", "0", "--no-kernel-events", "--preroll", "0", "--adapter-scans", "0"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
