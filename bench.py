@@ -93,7 +93,7 @@ def run_other_mode(args, rank, local_rank, world, coll_dev):
     import torch
     import torch.distributed as dist
     from semantic_suma_amd import core, synth
-    from semantic_suma_amd.distributed import HipEngine, gather_poses, lpt_assign, run_hypotheses, run_sequences
+    from semantic_suma_amd.distributed import gather_poses, lpt_assign, run_hypotheses_hip, run_sequences_hip
     from semantic_suma_amd.types import params_with_size
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
 
@@ -109,16 +109,21 @@ def run_other_mode(args, rank, local_rank, world, coll_dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    up = core.Context(params_with_size(W, H, max_surfels=65536), device=local_rank)  # only to place scans in HBM
+
+    def resident(sc):
+        return tuple(up.device_array(x) for x in sc) + (sc[0].shape[0],)
+
     if args.mode == "hypotheses":
         n_hyp = 8
         p = params_with_size(W, H, max_iterations=args.icp_iterations, stopping_threshold=0.0, delta=0.0)
-        scans = [synth.generate_scan(k, n_azimuth=W, height=H)[:3] for k in range(Wu + K)]
-        eng = HipEngine(p, device=local_rank)
-        run_hypotheses(eng, scans[:Wu], n_hyp, rank, world, gather=lambda a: gather_poses(a, device=coll_dev))
-        eng2 = HipEngine(p, device=local_rank)  # fresh map for the timed run (the warm-up warmed the process, not the map)
+        scans = [resident(synth.generate_scan(k, n_azimuth=W, height=H)[:3]) for k in range(Wu + K)]
+        gather = lambda a: gather_poses(a, device=coll_dev)  # noqa: E731
+        # warm-up: the process (module load, first-touch allocations), not the map -- the timed run starts a fresh one
+        run_hypotheses_hip(p, scans[:max(2, Wu)], n_hyp, rank, world, device=local_rank, gather=gather, on_device=True)
         barrier()
         t0 = time.perf_counter()
-        poses, winners = run_hypotheses(eng2, scans, n_hyp, rank, world, gather=lambda a: gather_poses(a, device=coll_dev))
+        poses, winners = run_hypotheses_hip(p, scans, n_hyp, rank, world, device=local_rank, gather=gather, on_device=True)
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         if rank == 0:
@@ -129,23 +134,27 @@ def run_other_mode(args, rank, local_rank, world, coll_dev):
                               "hypotheses_per_sec": n_hyp * (n - 1) / elapsed,
                               "config": {"workload": f"BASELINE configs[2]: {H}x{W}, {n_hyp} ICP hypotheses per scan "
                                                      f"({args.icp_iterations} GN iterations each) sharded over the ranks, one "
-                                                     "gather of 18 doubles per hypothesis and scan, map update with the winner "
-                                                     "on every rank",
+                                                     "exchange of 18 doubles per hypothesis and scan, map update with the winner "
+                                                     "on every rank; native host loop (suma_run_hypotheses), scans resident in HBM",
                                          "winners": winners[1:9], "pose_x_end": round(float(poses[-1][0, 3]), 3),
                                          "parallelism": f"hypothesis-sharded x{world}"}}))
         return
     # sequences11
     lengths_full = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # KITTI odometry 00-10
     scale = max(1, int(os.environ.get("SUMA_SEQ_SCALE", "32")))
+    conc = max(1, int(os.environ.get("SUMA_SEQ_CONCURRENT", "4")))
     lengths = [max(4, n // scale) for n in lengths_full]
     assign, loads = lpt_assign(lengths, world)
     p = params_with_size(W, H)
     mine = assign[rank]
-    cache = {s: [synth.generate_scan(1337 * (s + 1) + k, n_azimuth=W, height=H)[:3] for k in range(lengths[s])] for s in mine}
+    cache = {s: [resident(synth.generate_scan(1337 * (s + 1) + k, n_azimuth=W, height=H)[:3]) for k in range(lengths[s])]
+             for s in mine}
+    run_sequences_hip(p, {-1: cache[mine[0]][:3]} if mine else {}, device=local_rank, fixed_iterations=args.icp_iterations,
+                      max_concurrent=1, on_device=True)  # warm the process
     barrier()
     t0 = time.perf_counter()
-    res = run_sequences(mine, lambda: core.SurfelMapping(p, device=local_rank), lambda s: cache[s],
-                        fixed_iterations=args.icp_iterations, threads=True)
+    res = run_sequences_hip(p, cache, device=local_rank, fixed_iterations=args.icp_iterations, max_concurrent=conc,
+                            on_device=True)
     torch.cuda.synchronize()
     mine_s = time.perf_counter() - t0
     ends = np.zeros((len(lengths), 16))
@@ -162,7 +171,8 @@ def run_other_mode(args, rank, local_rank, world, coll_dev):
                           "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"BASELINE configs[3]: the 11 KITTI odometry sequence lengths / {scale} "
                                                  f"({lengths}), {H}x{W}, semantic ICP ({args.icp_iterations} GN iterations), "
-                                                 "LPT-assigned to the ranks, concurrent pipelines where a rank owns several",
+                                                 f"LPT-assigned to the ranks, up to {conc} concurrent pipelines per GPU; native "
+                                                 "host loop (suma_run_sequences), scans resident in HBM",
                                      "assignment": assign, "load_scans": loads,
                                      "idle_frac_per_rank": [round(1.0 - float(b) / elapsed, 3) for b in busy],
                                      "sequences_done": int((np.abs(allp).sum(axis=(0, 2)) > 0).sum()),

@@ -214,6 +214,15 @@ int suma_pipeline_get_pose(const suma_pipeline* s, int which, double pose[16]);
  * what checkLoopClosure compares candidates against (:538-539, :582, :727-729) */
 int suma_pipeline_result_new(suma_pipeline* s, suma_icp_stats* st);
 
+/* ---- several pose hypotheses per scan (BASELINE config 3; the reference runs several minimisations of one frame pair
+ *      from different starts in its loop-closure verification, SurfelMapping.cpp:662-779): between begin_scan and
+ *      update_map, INSTEAD of update_pose.  minimize_hypotheses runs n_hyp (<= 64) device-resident Gauss-Newton chains
+ *      as one batch against the rendered model (map_->newMapFrame(), as updatePose does, :384); apply_increment does
+ *      updatePose's pose bookkeeping (:453-474) for the increment the caller chose.  T0s / T_out: n_hyp x 16 doubles. */
+int suma_pipeline_minimize_hypotheses(suma_pipeline* s, const double* T0s, uint32_t n_hyp, int32_t fixed_iterations,
+                                      double* T_out, suma_icp_stats* stats);
+int suma_pipeline_apply_increment(suma_pipeline* s, const double increment[16]);
+
 int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
 int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
 int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);

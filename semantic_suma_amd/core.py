@@ -47,6 +47,31 @@ class LoopTrack(C.Structure):
                 ("passed", C.c_int32), ("pose_old", C.c_double * 16), ("composed", IcpStats), ("JtJ", C.c_double * 36)]
 
 
+class ScanRef(C.Structure):
+    """suma_scan_ref (include/suma_runner.h)"""
+    _fields_ = [("points", C.c_void_p), ("labels", C.c_void_p), ("probs", C.c_void_p), ("n", C.c_uint32)]
+
+
+class SequenceJob(C.Structure):
+    """suma_sequence_job"""
+    _fields_ = [("scans", C.POINTER(ScanRef)), ("n_scans", C.c_uint32), ("on_device", C.c_int32)]
+
+
+class SequenceResult(C.Structure):
+    """suma_sequence_result"""
+    _fields_ = [("status", C.c_int32), ("scans_done", C.c_uint32), ("map_surfels", C.c_uint32), ("track_loss", C.c_uint32),
+                ("end_pose", C.c_double * 16), ("seconds", C.c_double), ("error", C.c_char * 160)]
+
+
+class HypothesisJob(C.Structure):
+    """suma_hypothesis_job"""
+    _fields_ = [("scans", C.POINTER(ScanRef)), ("n_scans", C.c_uint32), ("on_device", C.c_int32),
+                ("perturbations", C.c_void_p), ("n_hyp", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_uint32)
+
+
 class IcpObjective(C.Structure):
     """suma_icp_objective (include/suma_hip.h): the parameters one Frame2Model object owns"""
     _fields_ = [("icp_max_distance", C.c_float), ("icp_max_angle", C.c_float), ("weight_function", C.c_int32),
@@ -146,6 +171,12 @@ def lib():
     L.suma_loop_closure_track.argtypes = [vp, vp, vp, vp, vp, f32, C.c_double, C.c_double, C.c_double, C.POINTER(LoopTrack)]
     L.suma_se3_log.argtypes = [vp, vp]
     L.suma_se3_log.restype = None
+    L.suma_pipeline_minimize_hypotheses.argtypes = [vp, vp, u32, i32, vp, vp]
+    L.suma_pipeline_apply_increment.argtypes = [vp, vp]
+    L.suma_run_sequences.argtypes = [C.POINTER(SumaParams), C.c_int, C.POINTER(SequenceJob), u32, u32, i32,
+                                     C.POINTER(SequenceResult)]
+    L.suma_run_hypotheses.argtypes = [C.POINTER(SumaParams), C.c_int, C.POINTER(HypothesisJob), i32, EXCHANGE_FN, vp, vp,
+                                      vp, C.c_char_p]
     L.suma_pipeline_last_increment.argtypes = [vp, vp]
     L.suma_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_pipeline_timestamp.restype = u32
@@ -650,6 +681,81 @@ def loop_closure_track(ctx, current, last_pose_old, last_increment, pose_new, co
     return _loop_track(r)
 
 
+def _scan_refs(scans, on_device):
+    """list of (points, labels, probs[, n]) -> (ScanRef array, keep-alive list).  Host scans: numpy arrays; device
+    scans: (d_points, d_labels, d_probs, n) addresses from Context.device_array."""
+    refs = (ScanRef * max(1, len(scans)))()
+    keep = []
+    for k, sc in enumerate(scans):
+        if on_device:
+            refs[k] = ScanRef(int(sc[0]), int(sc[1]) if sc[1] else None, int(sc[2]) if sc[2] else None, int(sc[3]))
+        else:
+            pts = np.ascontiguousarray(sc[0], dtype=np.float32).reshape(-1, 4)
+            lab = None if sc[1] is None else np.ascontiguousarray(sc[1], dtype=np.float32)
+            prob = None if sc[2] is None else np.ascontiguousarray(sc[2], dtype=np.float32)
+            keep.append((pts, lab, prob))
+            refs[k] = ScanRef(pts.ctypes.data, None if lab is None else lab.ctypes.data,
+                              None if prob is None else prob.ctypes.data, pts.shape[0])
+    return refs, keep
+
+
+def run_sequences_native(params: SumaParams, sequences, device: int = 0, fixed_iterations: int = 0,
+                         max_concurrent: int = 4, on_device: bool = False):
+    """BASELINE configs[3] on one GPU: suma_run_sequences (include/suma_runner.h) -- the sequences (lists of scans) in
+    the order given, at most max_concurrent at a time, each through a pipeline and a host thread of its own; no
+    interpreter between two scans.  Returns one dict per sequence."""
+    L = lib()
+    n = len(sequences)
+    jobs = (SequenceJob * max(1, n))()
+    keep = []
+    for j, scans in enumerate(sequences):
+        refs, ka = _scan_refs(scans, on_device)
+        keep.append((refs, ka))
+        jobs[j] = SequenceJob(refs, len(scans), 1 if on_device else 0)
+    res = (SequenceResult * max(1, n))()
+    rc = L.suma_run_sequences(C.byref(params), device, jobs, n, max_concurrent, fixed_iterations, res)
+    out = [dict(status=r.status, scans_done=r.scans_done, map_surfels=r.map_surfels, track_loss=r.track_loss,
+                end_pose=np.array(r.end_pose[:]).reshape(4, 4).T.copy(), seconds=r.seconds, error=r.error.decode())
+           for r in res[:n]]
+    if rc != 0:
+        raise SumaError(f"suma_run_sequences failed ({rc}): {[o['error'] for o in out if o['status']]}")
+    return out
+
+
+def run_hypotheses_native(params: SumaParams, scans, perturbations, rank: int = 0, world: int = 1, device: int = 0,
+                          fixed_iterations: int = 0, exchange=None, on_device: bool = False):
+    """BASELINE configs[2]: suma_run_hypotheses -- per scan len(perturbations) Gauss-Newton chains from
+    lastIncrement * perturbations[k] (hypothesis k on rank k % world), one exchange per scan (exchange(local) -> the
+    element-wise sum over the ranks of the [n_hyp, 18] table), the same winner on every rank, map update with it.
+    Returns (poses [n, 4, 4], winners)."""
+    L = lib()
+    refs, keep = _scan_refs(scans, on_device)
+    D = np.ascontiguousarray(np.asarray(perturbations, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
+    n_hyp, n = D.shape[0], len(scans)
+    job = HypothesisJob(refs, n, 1 if on_device else 0, D.ctypes.data, n_hyp, rank, world)
+    poses = np.zeros((max(1, n), 16), dtype=np.float64)
+    winners = np.zeros(max(1, n), dtype=np.int32)
+    err = C.create_string_buffer(160)
+    failure = []
+
+    def _cb(user, local, allp, count):
+        try:
+            loc = np.ctypeslib.as_array(local, shape=(count,)).reshape(n_hyp, 18).copy()
+            tot = np.ascontiguousarray(exchange(loc), dtype=np.float64).reshape(-1)
+            np.ctypeslib.as_array(allp, shape=(count,))[:] = tot
+            return 0
+        except Exception as e:  # noqa: BLE001 -- reported through the return code
+            failure.append(repr(e))
+            return -2
+
+    cb = EXCHANGE_FN(_cb) if (world > 1 and exchange is not None) else C.cast(None, EXCHANGE_FN)
+    rc = L.suma_run_hypotheses(C.byref(params), device, C.byref(job), fixed_iterations, cb, None, _ptr(poses), _ptr(winners),
+                               err)
+    if rc != 0:
+        raise SumaError(f"suma_run_hypotheses failed ({rc}): {err.value.decode()} {failure}")
+    return poses[:n].reshape(n, 4, 4).transpose(0, 2, 1).copy(), [int(w) for w in winners[:n]]
+
+
 class SurfelMapping:
     """SurfelMapping::processScan (SurfelMapping.cpp:175-210).  processScan* run a scan in one call; beginScan /
     updatePose / updateMap are its phases for hosts that run loop closures between them (verifyLoopClosure,
@@ -786,6 +892,20 @@ class SurfelMapping:
                                                                max_increment_difference, C.byref(r)),
                        "suma_pipeline_track_loop_closure")
         return _loop_track(r)
+
+    def minimizeHypotheses(self, starts, fixed_iterations: int = 0):
+        """n Gauss-Newton chains as one batch against the rendered model, between beginScan and applyIncrement"""
+        T0 = np.ascontiguousarray(np.asarray(starts, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
+        n = T0.shape[0]
+        out = np.zeros((n, 4, 4), dtype=np.float64)
+        st = (IcpStats * n)()
+        self.ctx.check(self.L.suma_pipeline_minimize_hypotheses(self.h, _ptr(T0), n, fixed_iterations, _ptr(out), st),
+                       "suma_pipeline_minimize_hypotheses")
+        return out.transpose(0, 2, 1).copy(), [s.as_dict() for s in st]
+
+    def applyIncrement(self, increment):
+        T = _cm(increment, np.float64)
+        self.ctx.check(self.L.suma_pipeline_apply_increment(self.h, _ptr(T)), "suma_pipeline_apply_increment")
 
     def getCurrentPose(self):
         T = np.zeros((4, 4), dtype=np.float64)

@@ -1504,6 +1504,43 @@ extern "C" int suma_pipeline_update_pose(suma_pipeline* s, int32_t fixed_iterati
 }
 extern "C" int suma_pipeline_update_map(suma_pipeline* s) { return pipeline_update_map_impl(s); }
 
+/* ---- hypothesis tracking on the scan pipeline (BASELINE config 3; the reference's pattern of several minimisations of
+ *      one frame pair from different starts, SurfelMapping.cpp:662-779, applied to odometry): between begin_scan and
+ *      update_map, INSTEAD of update_pose -- the caller minimises a batch of starts against the rendered model
+ *      (map_->newMapFrame(), as updatePose does, :384), picks one result and applies it. */
+extern "C" int suma_pipeline_minimize_hypotheses(suma_pipeline* s, const double* T0s, uint32_t n_hyp,
+                                                 int32_t fixed_iterations, double* T_out, suma_icp_stats* stats) {
+  if (!s || !T0s || !T_out || n_hyp == 0 || n_hyp > SUMA_MAX_HYP) return SUMA_ERR_INVALID;
+  suma_ctx* c = s->c;
+  if (s->phase != 1) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_minimize_hypotheses: between suma_pipeline_begin_scan and suma_pipeline_apply_increment");
+  suma_params saved = c->p;
+  if (fixed_iterations > 0) {
+    c->p.max_iterations = (uint32_t)fixed_iterations;
+    c->p.stopping_threshold = 0.0f;
+    c->p.delta = 0.0f;
+  }
+  c->icp_current = s->current_frame;
+  c->icp_model = c->new_frame;
+  int r = suma_icp_minimize_batch(c, T0s, n_hyp, T_out, stats);
+  c->p = saved;
+  return r;
+}
+/* the pose bookkeeping of updatePose (SurfelMapping.cpp:453-474) for an increment chosen by the caller */
+extern "C" int suma_pipeline_apply_increment(suma_pipeline* s, const double increment[16]) {
+  if (!s || !increment) return SUMA_ERR_INVALID;
+  if (s->phase != 1) return fail(s->c, SUMA_ERR_INVALID, "suma_pipeline_apply_increment: call suma_pipeline_begin_scan first");
+  memcpy(s->last_pose, s->current_pose, sizeof(s->last_pose));
+  double np[16];
+  mul4_d(s->current_pose, increment, np);
+  memcpy(s->current_pose, np, sizeof(np));
+  memcpy(s->last_pose_old, s->pose_old, sizeof(s->last_pose_old));
+  memcpy(s->pose_old, np, sizeof(np));
+  memcpy(s->pose_new, np, sizeof(np));
+  memcpy(s->last_increment, increment, 16 * sizeof(double));
+  s->phase = 2;
+  return SUMA_OK;
+}
+
 /* integrateLoopClosures, SurfelMapping.cpp:211-250 (the part behind the optimiser's future) */
 extern "C" int suma_pipeline_integrate_loop_closures(suma_pipeline* s, const float* poses16, uint32_t n,
                                                      const double difference[16]) {

@@ -26,12 +26,12 @@ def lpt_assign(lengths, world_size: int):
     return out, loads
 
 
-def hypothesis_starts(T0: np.ndarray, n: int, seed: int = 1234, max_t: float = 0.2, max_deg: float = 2.0):
-    """n start poses T0 * exp(xi_k), xi_k ~ U(+-max_t m, +-max_deg deg) with seed 1234 + k; k = 0 unperturbed
+def hypothesis_perturbations(n: int, seed: int = 1234, max_t: float = 0.2, max_deg: float = 2.0):
+    """n rigid motions D_k = exp(xi_k), xi_k ~ U(+-max_t m, +-max_deg deg) with seed 1234 + k; D_0 = identity
     (SURVEY.md 8d config 3).  Deterministic and identical on every rank."""
     out = []
     for k in range(n):
-        T = np.array(T0, dtype=np.float64)
+        D = np.eye(4)
         if k:
             rng = np.random.default_rng(seed + k)
             t = rng.uniform(-max_t, max_t, 3)
@@ -39,11 +39,16 @@ def hypothesis_starts(T0: np.ndarray, n: int, seed: int = 1234, max_t: float = 0
             th = float(np.linalg.norm(w))
             K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
             R = np.eye(3) if th < 1e-12 else np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
-            D = np.eye(4)
             D[:3, :3], D[:3, 3] = R, t
-            T = T @ D
-        out.append(T)
+        out.append(D)
     return out
+
+
+def hypothesis_starts(T0: np.ndarray, n: int, seed: int = 1234, max_t: float = 0.2, max_deg: float = 2.0):
+    """n start poses T0 * D_k (hypothesis_perturbations), formed in the fixed operation order of mul4 -- the native
+    runner (suma_run_hypotheses) forms the very same products, k = 0 included."""
+    T0 = np.array(T0, dtype=np.float64)
+    return [mul4(T0, D) for D in hypothesis_perturbations(n, seed, max_t, max_deg)]
 
 
 def pick_winner(stats) -> int:
@@ -200,3 +205,31 @@ def run_sequences(my_sequences, make_pipeline, scans_of, fixed_iterations: int =
     if errors:
         raise RuntimeError(f"sequence runs failed: {errors}")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The same two runners with the host loop in C++ (include/suma_runner.h, csrc/suma_runner.hip): no interpreter between
+# two scans.  The Python loops above stay as the reference orchestration (the world-2 gloo tests drive them over a
+# stand-in engine on CPU); tests/test_gpu_dist.py demands identical poses, winners and maps from both.
+# ---------------------------------------------------------------------------------------------------------------
+
+def run_hypotheses_hip(params, scans, n_hyp: int, rank: int = 0, world: int = 1, device: int = 0,
+                       fixed_iterations: int = 0, gather=gather_poses, on_device: bool = False):
+    """BASELINE config 3 through suma_run_hypotheses.  One exchange per scan: every rank's [n_hyp, 18] table is
+    gathered with `gather` and summed (each row is owned by exactly one rank).  Returns (poses [n, 4, 4], winners)."""
+    from . import core
+    exchange = (lambda local: gather(local).sum(axis=0)) if world > 1 else None
+    return core.run_hypotheses_native(params, scans, hypothesis_perturbations(n_hyp), rank, world, device,
+                                      fixed_iterations, exchange, on_device)
+
+
+def run_sequences_hip(params, sequences, device: int = 0, fixed_iterations: int = 0, max_concurrent: int = 4,
+                      on_device: bool = False):
+    """BASELINE config 4, one rank's share, through suma_run_sequences: `sequences` = {sequence id: list of scans};
+    the longest sequence starts first (LPT inside the rank), at most max_concurrent pipelines at a time.
+    Returns {sequence id: (n_scans, final pose)} like run_sequences."""
+    from . import core
+    order = sorted(sequences, key=lambda s: (-len(sequences[s]), s))
+    res = core.run_sequences_native(params, [sequences[s] for s in order], device, fixed_iterations, max_concurrent,
+                                    on_device)
+    return {s: (r["scans_done"], r["end_pose"]) for s, r in zip(order, res)}

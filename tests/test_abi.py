@@ -34,6 +34,25 @@ def test_every_declared_symbol_is_exported(built):
     assert b"gfx950" in C.c_char_p(C.cast(L.suma_version, C.CFUNCTYPE(C.c_char_p))()).value
 
 
+def test_runner_header_is_exported_and_layouts_match(built, tmp_path):
+    """include/suma_runner.h (native host loops for the replica configurations): symbols in libsuma_hip.so, struct
+    layouts equal to the ctypes mirrors"""
+    L = C.CDLL(built.LIB_PATH)
+    names = declared_functions("suma_runner.h")
+    assert {"suma_run_sequences", "suma_run_hypotheses"} <= set(names)
+    assert not [n for n in names if not hasattr(L, n)]
+    from semantic_suma_amd.core import HypothesisJob, LoopTrack, ScanRef, SequenceJob, SequenceResult
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "suma_runner.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n",'
+                   "sizeof(suma_scan_ref),sizeof(suma_sequence_job),sizeof(suma_sequence_result),"
+                   "sizeof(suma_hypothesis_job),sizeof(suma_loop_track));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(ScanRef), C.sizeof(SequenceJob), C.sizeof(SequenceResult), C.sizeof(HypothesisJob),
+                     C.sizeof(LoopTrack)]
+
+
 def test_dist_library_exports_its_header(built):
     """libsuma_hip_dist.so (the RCCL gather, kept out of libsuma_hip.so) exports what include/suma_hip_dist.h declares;
     libsuma_hip.so itself must not depend on RCCL"""
@@ -83,7 +102,7 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "pyoracle" not in text and "libsuma_oracle" not in text and "oracle/" not in text, f
-    for f in ("suma_hip.h", "suma_types.h", "suma_detmath.h"):
+    for f in ("suma_hip.h", "suma_types.h", "suma_detmath.h", "suma_runner.h", "suma_adapter.hpp"):
         assert "ora_" not in open(os.path.join(ROOT, "include", f)).read()
 
 

@@ -84,6 +84,58 @@ def test_sequences_as_concurrent_pipelines():
         assert a[s][0] == lengths[s] and np.array_equal(a[s][1], b[s][1]), f"sequence {s}"
 
 
+def test_native_sequence_runner_equals_the_python_runner():
+    """suma_run_sequences (C++ host loop, one thread per pipeline) against run_sequences, from host arrays (staged two
+    scans ahead) and from scans resident in HBM"""
+    from semantic_suma_amd import core, synth
+    from semantic_suma_amd.distributed import run_sequences, run_sequences_hip
+    p = params_with_size(W)
+    lengths = {0: 6, 1: 4, 2: 3, 3: 5}
+    seqs = {s: [synth.generate_scan(50 * s + k, n_azimuth=W)[:3] for k in range(n)] for s, n in lengths.items()}
+    ref = run_sequences(list(lengths), lambda: core.SurfelMapping(p), lambda s: seqs[s], fixed_iterations=10, threads=False)
+    a = run_sequences_hip(p, seqs, fixed_iterations=10, max_concurrent=3)
+    ctx = core.Context(p)
+    dev = {s: [tuple(ctx.device_array(x) for x in sc) + (sc[0].shape[0],) for sc in seqs[s]] for s in seqs}
+    b = run_sequences_hip(p, dev, fixed_iterations=10, max_concurrent=2, on_device=True)
+    for s, n in lengths.items():
+        assert a[s][0] == n and b[s][0] == n
+        assert np.array_equal(a[s][1], ref[s][1]), f"sequence {s}: host arrays"
+        assert np.array_equal(b[s][1], ref[s][1]), f"sequence {s}: resident scans"
+
+
+def test_native_hypothesis_runner_equals_the_python_runner():
+    """suma_run_hypotheses (C++ host loop on the scan pipeline's phases) against run_hypotheses over HipEngine: the same
+    poses and winners from one rank, and from two ranks that exchange their tables (two threads, one device)"""
+    import threading
+    from semantic_suma_amd import synth
+    from semantic_suma_amd.distributed import HipEngine, run_hypotheses, run_hypotheses_hip
+    p = params_with_size(W, max_iterations=8)
+    scans = [synth.generate_scan(k, n_azimuth=W)[:3] for k in range(N_SCANS)]
+    ref_poses, ref_winners = run_hypotheses(HipEngine(p, device=0), scans, N_HYP)
+    poses, winners = run_hypotheses_hip(p, scans, N_HYP)
+    assert winners == ref_winners and np.array_equal(poses, ref_poses)
+    # two ranks in one process: the exchange is a barrier + sum of the two tables
+    tables, out, barrier = {}, {}, threading.Barrier(2)
+
+    def exchange_for(rank):
+        def gather(local):
+            tables[rank] = np.array(local)
+            barrier.wait()
+            tot = np.stack([tables[0], tables[1]])
+            barrier.wait()
+            return tot
+        return gather
+
+    def run(rank):
+        out[rank] = run_hypotheses_hip(p, scans, N_HYP, rank=rank, world=2, gather=exchange_for(rank))
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    [t.start() for t in th]
+    [t.join(timeout=600) for t in th]
+    for r in range(2):
+        assert out[r][1] == ref_winners and np.array_equal(out[r][0], ref_poses), f"rank {r}"
+
+
 def test_bench_contract_with_two_ranks_on_one_device():
     """bench.py's N > 1 path end to end -- torch.distributed.run, one process per rank, barrier + max-over-ranks timing,
     the pose gather, rank 0's JSON line -- with two ranks sharing this box's one GPU (gloo; RCCL needs a GPU per rank)"""
