@@ -194,6 +194,10 @@ def main():
     ap.add_argument("--preroll", type=int, default=300,
                     help="scans of the same sequence processed (untimed) before the timed region, so that the map has its "
                          "steady size; 0 = time the sequence from its first scan (e.g. --steps 4541 --preroll 0)")
+    ap.add_argument("--max-surfels", type=int, default=0,
+                    help="map capacity (0 = the reference's maxNumSurfels_ = 2048 * 2048, SurfelMap.h:87; the synthetic loop "
+                         "is driven several times without loop closures, so a full 4541-scan run layers the map and needs "
+                         "the reference's own alternative 4096 * 4096)")
     ap.add_argument("--adapter-scans", type=int, default=120,
                     help="scans of the class-by-class adapter path timing (tools/adapter_bench.cpp; 0 = skip)")
     ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11"],
@@ -235,7 +239,8 @@ def main():
     kitti_dir = os.environ.get("SUMA_KITTI_DIR")  # e.g. .../sequences/00 ; absent on the build / bench machines
     # the reference fetches label i+4 / prob i+5 for point i (Preprocessing.cpp:142-145, an offset bug that is harmless
     # on its zero-padded network output); reproduced for parity on synthetic data, switched off for real labels
-    p = params_with_size(W, H, label_offset=0, prob_offset=0) if kitti_dir else params_with_size(W, H)
+    extra = dict(max_surfels=args.max_surfels) if args.max_surfels else {}
+    p = params_with_size(W, H, label_offset=0, prob_offset=0, **extra) if kitti_dir else params_with_size(W, H, **extra)
     pipe = core.SurfelMapping(p, device=local_rank)
     ctx = pipe.ctx
 

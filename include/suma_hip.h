@@ -164,6 +164,8 @@ int suma_map_counts(suma_ctx* ctx, uint32_t* n_updated, uint32_t* n_new, uint32_
  *      fixed_iterations > 0 runs exactly that many GN iterations (bench mode). */
 int suma_pipeline_create(const suma_params* params, int hip_device, suma_pipeline** out);
 void suma_pipeline_destroy(suma_pipeline* s);
+/* SurfelMapping::reset (SurfelMapping.cpp:131-169): empty map, identity poses, timestamp 0 */
+int suma_pipeline_reset(suma_pipeline* s);
 suma_ctx* suma_pipeline_ctx(suma_pipeline* s);
 int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
                                uint32_t n, int32_t fixed_iterations);

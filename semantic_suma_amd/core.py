@@ -171,6 +171,7 @@ def lib():
     L.suma_loop_closure_track.argtypes = [vp, vp, vp, vp, vp, f32, C.c_double, C.c_double, C.c_double, C.POINTER(LoopTrack)]
     L.suma_se3_log.argtypes = [vp, vp]
     L.suma_se3_log.restype = None
+    L.suma_pipeline_reset.argtypes = [vp]
     L.suma_pipeline_minimize_hypotheses.argtypes = [vp, vp, u32, i32, vp, vp]
     L.suma_pipeline_apply_increment.argtypes = [vp, vp]
     L.suma_run_sequences.argtypes = [C.POINTER(SumaParams), C.c_int, C.POINTER(SequenceJob), u32, u32, i32,
@@ -892,6 +893,10 @@ class SurfelMapping:
                                                                max_increment_difference, C.byref(r)),
                        "suma_pipeline_track_loop_closure")
         return _loop_track(r)
+
+    def reset(self):
+        """SurfelMapping::reset (SurfelMapping.cpp:131-169)"""
+        self.ctx.check(self.L.suma_pipeline_reset(self.h), "suma_pipeline_reset")
 
     def minimizeHypotheses(self, starts, fixed_iterations: int = 0):
         """n Gauss-Newton chains as one batch against the rendered model, between beginScan and applyIncrement"""

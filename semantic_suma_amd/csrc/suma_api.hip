@@ -1504,6 +1504,32 @@ extern "C" int suma_pipeline_update_pose(suma_pipeline* s, int32_t fixed_iterati
 }
 extern "C" int suma_pipeline_update_map(suma_pipeline* s) { return pipeline_update_map_impl(s); }
 
+/* SurfelMapping::reset (SurfelMapping.cpp:131-169): empty map, identity poses, timestamp 0 -- the object is as new */
+extern "C" int suma_pipeline_reset(suma_pipeline* s) {
+  if (!s) return SUMA_ERR_INVALID;
+  suma_ctx* c = s->c;
+  int r = suma_synchronize(c);
+  if (r) return r;
+  if (c->gate_pending) c->gate_pending = 0; /* both streams have drained */
+  if (c->k7.valid) CK(launch_clear_index_zbuf(c)); /* an index-map splat nobody will consume */
+  r = map_reset_impl(c);
+  if (r) return r;
+  s->stats_pending = false;
+  memset(&s->stats, 0, sizeof(s->stats));
+  s->timestamp = 0;
+  s->track_loss = 0;
+  s->phase = 0;
+  eye_d(s->current_pose);
+  eye_d(s->last_pose);
+  eye_d(s->pose_old);
+  eye_d(s->pose_new);
+  eye_d(s->last_increment);
+  eye_d(s->last_pose_old);
+  c->obj_set = false;
+  c->k8_fused_frame = nullptr;
+  return suma_synchronize(c);
+}
+
 /* ---- hypothesis tracking on the scan pipeline (BASELINE config 3; the reference's pattern of several minimisations of
  *      one frame pair from different starts, SurfelMapping.cpp:662-779, applied to odometry): between begin_scan and
  *      update_map, INSTEAD of update_pose -- the caller minimises a batch of starts against the rendered model

@@ -24,30 +24,19 @@ static void set_error(char* dst, size_t cap, const std::string& msg) {
   dst[cap - 1] = 0;
 }
 
-/* one sequence through a pipeline of its own (SurfelMapping::processScan scan after scan) */
-static void run_one_sequence(const suma_params* params, int device, const suma_sequence_job& job, int32_t fixed_iterations,
+/* one sequence through pipeline `s` (SurfelMapping::processScan scan after scan), which is reset first */
+static void run_one_sequence(suma_pipeline* s, const suma_sequence_job& job, int32_t fixed_iterations,
                              suma_sequence_result* res) {
   memset(res, 0, sizeof(*res));
-  if (hipSetDevice(device) != hipSuccess) {
-    res->status = SUMA_ERR_HIP;
-    set_error(res->error, sizeof(res->error), "hipSetDevice failed");
-    return;
-  }
-  suma_pipeline* s = nullptr;
-  int r = suma_pipeline_create(params, device, &s);
-  if (r != SUMA_OK) {
-    res->status = r;
-    set_error(res->error, sizeof(res->error), std::string("suma_pipeline_create: ") + suma_last_error(nullptr));
-    return;
-  }
+  int r = suma_pipeline_reset(s);
   const double t0 = now_s();
   uint32_t k = 0;
-  if (job.on_device) {
+  if (r == SUMA_OK && job.on_device) {
     for (; k < job.n_scans && r == SUMA_OK; ++k) {
       const suma_scan_ref& sc = job.scans[k];
       r = suma_pipeline_process_scan_device(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations);
     }
-  } else {
+  } else if (r == SUMA_OK) {
     /* host arrays: keep two scans staged beyond the one being processed (suma_ingest.hip) */
     uint32_t staged = 0;
     for (; k < job.n_scans && r == SUMA_OK; ++k) {
@@ -68,7 +57,6 @@ static void run_one_sequence(const suma_params* params, int device, const suma_s
   res->track_loss = suma_pipeline_track_loss(s);
   uint32_t n = 0;
   if (suma_map_size(suma_pipeline_ctx(s), &n) == SUMA_OK) res->map_surfels = n;
-  suma_pipeline_destroy(s);
 }
 
 extern "C" int suma_run_sequences(const suma_params* params, int hip_device, const suma_sequence_job* jobs,
@@ -79,12 +67,23 @@ extern "C" int suma_run_sequences(const suma_params* params, int hip_device, con
   if (max_concurrent == 0) max_concurrent = 1;
   const uint32_t n_workers = max_concurrent < n_jobs ? max_concurrent : n_jobs;
   std::atomic<uint32_t> next(0);
+  /* one pipeline per WORKER, reset between its sequences (SurfelMapping::reset): a pipeline owns several GB of map
+   * and cache arena, creating one per sequence would cost more than a short sequence takes */
   auto worker = [&]() {
+    suma_pipeline* s = nullptr;
+    int rc = (hipSetDevice(hip_device) == hipSuccess) ? suma_pipeline_create(params, hip_device, &s) : SUMA_ERR_HIP;
     for (;;) {
       const uint32_t j = next.fetch_add(1);
-      if (j >= n_jobs) return;
-      run_one_sequence(params, hip_device, jobs[j], fixed_iterations, &results[j]);
+      if (j >= n_jobs) break;
+      if (rc != SUMA_OK) {
+        memset(&results[j], 0, sizeof(results[j]));
+        results[j].status = rc;
+        set_error(results[j].error, sizeof(results[j].error), std::string("suma_pipeline_create: ") + suma_last_error(nullptr));
+        continue;
+      }
+      run_one_sequence(s, jobs[j], fixed_iterations, &results[j]);
     }
+    if (s) suma_pipeline_destroy(s);
   };
   std::vector<std::thread> th;
   for (uint32_t w = 1; w < n_workers; ++w) th.emplace_back(worker);

@@ -128,3 +128,25 @@ def test_scripted_loop_closing_run(hip, oracle_lib):
     assert hp.map.size() == op.ctx.map_size() and hp.map.size() > 100000
     gt = np.linalg.inv(ls.circle_pose(0)) @ ls.circle_pose(n - 1)
     assert np.linalg.norm((np.linalg.inv(hp.getCurrentPose()) @ gt)[:3, 3]) < 1.0
+
+
+def test_pipeline_reset_is_a_fresh_pipeline(hip):
+    """SurfelMapping::reset (SurfelMapping.cpp:131-169): after a reset -- also one issued between update_pose and update_map,
+    with an index-map splat pending -- the pipeline reproduces a new object's results bit for bit"""
+    p = params_with_size(900)
+    scans = [get_scan(k, 900, True)[:3] for k in range(4)]
+    fresh = hip.SurfelMapping(p)
+    for sc in scans:
+        fresh.processScan(*sc, fixed_iterations=8)
+    used = hip.SurfelMapping(p)
+    for sc in scans[::-1]:
+        used.processScan(*sc, fixed_iterations=8)
+    used.beginScan(*scans[0])
+    used.updatePose(8)      # leaves the fused K7 splat in the z-buffer
+    used.reset()
+    assert used.timestamp() == 0 and used.map.size() == 0 and np.array_equal(used.getCurrentPose(), np.eye(4))
+    for sc in scans:
+        used.processScan(*sc, fixed_iterations=8)
+    assert np.array_equal(used.getCurrentPose(), fresh.getCurrentPose())
+    assert used.lastStats().as_dict() == fresh.lastStats().as_dict()
+    assert used.map.getAllSurfels().tobytes() == fresh.map.getAllSurfels().tobytes()

@@ -23,12 +23,17 @@ def main():
     ap.add_argument("--scans", type=int, default=4541)
     ap.add_argument("--every", type=int, default=50)
     ap.add_argument("--threads", type=int, default=16)
+    ap.add_argument("--max-surfels", type=int, default=4096 * 4096,
+                    help="map capacity.  The synthetic loop (975 m) is driven 5.1 times WITHOUT loop closures, both straights lie "
+                         "inside one 90 m submap window, so every lap adds a drifted layer: the map passes the reference's "
+                         "maxNumSurfels_ = 2048 * 2048 (SurfelMap.h:87, where the reference would silently truncate and this "
+                         "library reports SUMA_ERR_CAPACITY) around scan 1500.  Default: the reference's own alternative 4096 * 4096")
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "long_parity.json"))
     args = ap.parse_args()
     from semantic_suma_amd import core
     from semantic_suma_amd.types import params_with_size
     from oracle import pyoracle
-    p = params_with_size(W, H)
+    p = params_with_size(W, H, max_surfels=args.max_surfels)
     hp, op = core.SurfelMapping(p), pyoracle.OraclePipeline(p, threads=args.threads)
     t0 = time.time()
     N = args.scans
@@ -66,7 +71,7 @@ def main():
     drift = float(np.linalg.norm((np.linalg.inv(hp.getCurrentPose()) @ gt)[:3, 3]))
     res = {"what": "BASELINE configs[1] full sequence: HIP pipeline == CPU oracle, bit for bit", "scans": N, "width": W, "height": H,
            "pose_and_statistics_compared": N, "surfel_buffers_compared": compared, "submap_origins_visited": len(origins),
-           "max_map_surfels": max_map, "track_loss_scans": hp.trackLoss(), "drift_m_vs_ground_truth": round(drift, 3),
+           "max_map_surfels": max_map, "max_surfels_capacity": args.max_surfels, "track_loss_scans": hp.trackLoss(), "drift_m_vs_ground_truth": round(drift, 3),
            "laps_of_the_synthetic_loop": round(N * 1.1 / (2 * 450.0 + 2 * np.pi * 12.0), 2),
            "hip_seconds_incl_host_upload_and_readback": round(t_hip, 1), "oracle_seconds": round(t_ora, 1),
            "oracle_threads": args.threads, "result": "equal"}
