@@ -53,6 +53,24 @@ def hbm_traffic(label, width, height):
         return None
 
 
+def cached_scan(k, W, H):
+    """synthetic scan k; with SUMA_SCAN_CACHE=<dir> the generated arrays are kept there (A/B loops inside one GPU session
+    run bench.py many times on the same scans: generation is ~25 ms per scan, a load ~2 ms)"""
+    from semantic_suma_amd import synth
+    d = os.environ.get("SUMA_SCAN_CACHE")
+    if not d:
+        return synth.generate_scan(k, n_azimuth=W, height=H)[:3]
+    path = os.path.join(d, f"scan_{W}x{H}_{k:06d}.npz")
+    if os.path.exists(path):
+        z = np.load(path)
+        return z["pts"], z["lab"], z["prob"]
+    pts, lab, prob = synth.generate_scan(k, n_azimuth=W, height=H)[:3]
+    os.makedirs(d, exist_ok=True)
+    np.savez(path + ".tmp.npz", pts=pts, lab=lab, prob=prob)
+    os.replace(path + ".tmp.npz", path)
+    return pts, lab, prob
+
+
 def adapter_path(scans, W, H, iterations):
     """compile and run tools/adapter_bench.cpp on the first scans of the sequence (a process of its own beside this
     one: its contexts are created after the timed region is over).  None if no compiler is at hand."""
@@ -266,7 +284,7 @@ def main():
         if seq is not None:
             pts, lab, prob = seq[(k0 + k) % len(seq)]
         else:
-            pts, lab, prob, _ = synth.generate_scan(k0 + k, n_azimuth=W, height=H)
+            pts, lab, prob = cached_scan(k0 + k, W, H)
         scans.append((ctx.device_array(pts), ctx.device_array(lab), ctx.device_array(prob), pts.shape[0],
                       (pts, lab, prob) if (rank == 0 and k < max(args.cpu_scans, args.adapter_scans)) else None))
     t_gen = time.perf_counter() - t_gen
