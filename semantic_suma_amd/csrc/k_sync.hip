@@ -42,9 +42,3 @@ hipError_t flush_gate(suma_ctx* c) {
   c->gate_pending = 0;
   return launch_gate(c, c->stream, 0, seq);
 }
-hipError_t flush_aux(suma_ctx* c) {
-  if (!c->aux_pending) return hipSuccess;
-  const uint32_t seq = c->aux_pending;
-  c->aux_pending = 0;
-  return launch_gate(c, c->stream, 2, seq);
-}

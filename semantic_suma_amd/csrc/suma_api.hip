@@ -123,7 +123,6 @@ static void prof_collect(suma_ctx* c) {
   if (c->prof_events.empty()) return;
   hipStreamSynchronize(c->stream);
   if (c->side_stream) hipStreamSynchronize(c->side_stream);
-  if (c->aux_stream) hipStreamSynchronize(c->aux_stream);
   for (auto& ev : c->prof_events) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ev.a, ev.b) == hipSuccess) {
@@ -192,10 +191,6 @@ static int frame_create_raw(suma_ctx* c, uint32_t w, uint32_t h, suma_frame** ou
 }
 
 static int read_state(suma_ctx* c) {
-  if (c->aux_pending) { /* an extraction beside the ctx stream moves the cache counters */
-    CK(hipStreamSynchronize(c->aux_stream));
-    c->aux_pending = 0;
-  }
   CK(hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
   c->known_surfels = c->h_ds->n_surfels;
@@ -203,7 +198,6 @@ static int read_state(suma_ctx* c) {
 }
 
 static int map_reset_impl(suma_ctx* c) {
-  if (c->aux_pending) CK(flush_aux(c));
   CK(hipMemsetAsync(c->ds, 0, sizeof(DevState), c->stream));
   CK(launch_fill_identity_poses(c));
   c->timestamp = 0;
@@ -272,10 +266,6 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   c->icp_current = c->icp_model = nullptr;
   c->obj_set = false;
   c->side_stream = nullptr;
-  c->aux_stream = nullptr;
-  c->extract_on_aux = 0;
-  c->aux_seq = 0;
-  c->aux_pending = 0;
   c->sync_flags = nullptr;
   c->zbuf_k1 = nullptr;
   c->filt_temp = nullptr;
@@ -382,10 +372,6 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipStreamSynchronize(c->side_stream);
     hipStreamDestroy(c->side_stream);
   }
-  if (c->aux_stream) {
-    hipStreamSynchronize(c->aux_stream);
-    hipStreamDestroy(c->aux_stream);
-  }
   for (auto& ev : c->prof_events) {
     hipEventDestroy(ev.a);
     hipEventDestroy(ev.b);
@@ -429,9 +415,7 @@ extern "C" int suma_set_params(suma_ctx* c, const suma_params* p) {
 extern "C" int suma_synchronize(suma_ctx* c) {
   if (!c) return SUMA_ERR_INVALID;
   if (c->side_stream) CK(hipStreamSynchronize(c->side_stream));
-  if (c->aux_stream) CK(hipStreamSynchronize(c->aux_stream));
   CK(hipStreamSynchronize(c->stream));
-  c->aux_pending = 0; /* whatever ran beside the ctx stream has completed */
   return SUMA_OK;
 }
 extern "C" void* suma_ctx_stream(suma_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -766,26 +750,7 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     uint32_t slot;
     int r = cache_slot_for(c, idx.first, idx.second, &slot);
     if (r) return r;
-    if (c->extract_on_aux && c->aux_stream) {
-      /* Scan pipeline: the extraction reads the map K9 / K10 have just written and writes the cache arena, which
-       * nothing of this scan reads -- it runs on a stream of its own, beside the post-update render, instead of
-       * adding a pass over the map (64 S bytes, ~30 us at 1 M surfels on every second scan) to the scan's critical
-       * path.  In-memory hand-offs as for the preprocessing (k_sync.hip): the aux stream starts behind the update,
-       * the ctx stream is ordered behind the extraction before the next kernel that shares its tickets, counters or
-       * arena (the next update / append / read-back: flush_aux). */
-      if (c->aux_pending) CK(flush_aux(c)); /* extractions of one update stay in order */
-      c->aux_seq += 1;
-      CK(launch_signal(c, c->stream, 1, c->aux_seq));
-      CK(launch_gate(c, c->aux_stream, 1, c->aux_seq));
-      c->ls = c->aux_stream;
-      hipError_t e = launch_extract(c, slot, cx, cy, c->p.submap_extent);
-      c->ls = c->stream;
-      CK(e);
-      CK(launch_signal(c, c->aux_stream, 2, c->aux_seq));
-      c->aux_pending = c->aux_seq;
-    } else {
-      CK(launch_extract(c, slot, cx, cy, c->p.submap_extent));
-    }
+    CK(launch_extract(c, slot, cx, cy, c->p.submap_extent));
     if (partially) break;
   }
   return SUMA_OK;
@@ -832,7 +797,6 @@ static int update_active_submaps(suma_ctx* c, const float* pose) {
 
 extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_frame* frame) {
   if (c && c->gate_pending) CK(flush_gate(c));
-  if (c && c->aux_pending) CK(flush_aux(c)); /* K9 / K10 share tickets, status words and DevState with K12 */
   if (!c || !pose || !frame) return SUMA_ERR_INVALID;
   if (frame->width != c->p.data_width || frame->height != c->p.data_height)
     return fail(c, SUMA_ERR_INVALID, "suma_map_update: frame size differs from data_width x data_height");
@@ -1221,7 +1185,6 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
    * the ctx stream (A/B measurements) */
   if (!getenv("SUMA_NO_SIDE_STREAM")) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        (!getenv("SUMA_NO_AUX_STREAM") && hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess) ||
         hipMalloc((void**)&c->zbuf_k1, c->P * 8) != hipSuccess ||
         hipMemsetAsync(c->zbuf_k1, 0xFF, c->P * 8, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) {
@@ -1512,9 +1475,7 @@ int pipeline_update_map_impl(suma_pipeline* s) {
   if (s->phase != 2) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_update_map: call suma_pipeline_update_pose first");
   float pc[16];
   cast_f(s->current_pose, pc);
-  c->extract_on_aux = 1;
   int r = suma_map_update(c, pc, s->current_frame);
-  c->extract_on_aux = 0;
   if (r) return r;
   r = map_render_dedup(c, pc, pc, conf_threshold(s), s->current_model);
   if (r) return r;

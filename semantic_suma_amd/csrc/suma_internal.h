@@ -101,10 +101,6 @@ struct suma_ctx {
   hipStream_t stream;      /* the ctx stream: everything the C-ABI promises to order */
   hipStream_t ls;          /* stream the launchers enqueue on: == stream, except while the scan pipeline enqueues side work */
   hipStream_t side_stream; /* scan pipeline only: work that is off the critical path of a scan (next scan's preprocessing) */
-  hipStream_t aux_stream;  /* scan pipeline only: K12 submap extraction, beside the post-update render (suma_api.hip, extract_surfels) */
-  int extract_on_aux;      /* set by the pipeline's update_map around suma_map_update */
-  uint32_t aux_seq;        /* hand-offs ctx -> aux (word 1: the updated map is complete) and aux -> ctx (word 2: K12 is done) */
-  uint32_t aux_pending;    /* != 0: the ctx stream has not yet been ordered behind this extraction (flush_aux) */
   uint32_t* sync_flags;    /* device: sequence words of the in-memory stream hand-offs (k_sync.hip) */
   uint32_t pre_seq;        /* preprocessing hand-offs issued so far */
   uint32_t gate_pending;   /* != 0: the ctx stream has not yet waited for this preprocessing hand-off (flush_gate) */
@@ -312,8 +308,6 @@ hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t se
 hipError_t launch_gate(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
 /* makes the ctx stream wait for the pending preprocessing hand-off (one-wave gate kernel) */
 hipError_t flush_gate(suma_ctx* c);
-/* makes the ctx stream wait for an extraction that runs on the aux stream */
-hipError_t flush_aux(suma_ctx* c);
 
 /* host helper shared by api + pipeline */
 void rigid_inverse_f(const float* m, float* out);
