@@ -195,6 +195,9 @@ struct UpdArgs {
       update_always;
   /* K11 */
   float cx, cy, extent;
+  /* K12 selection riding on K9 / K10: the tile that is extracted right after this update (ex_flags == NULL: none) */
+  uint8_t* ex_flags;
+  float ex_cx, ex_cy, ex_extent;
   /* K9 also records poses_[timestamp_] when K8 did not run as a kernel of its own */
   float* poses_w;
   float* poses_inv_w;
@@ -252,11 +255,14 @@ struct Surfel4 {
   float4 a, b, c, d; /* pos+radius | normal+confidence | timestamp,color,weight,count | semantic */
 };
 
-/* K11 predicate, copy_surfels.vert:38-56 */
-__device__ __forceinline__ bool in_active_area(const UpdArgs& a, const Surfel4& s) {
+/* K11 predicate, copy_surfels.vert:38-56.  *in_tile: the K12 predicate (extract_surfels.vert:46-64) for the tile this
+ * update flags -- the same world position (pose entry x record), evaluated here so that K12 need not recompute it for
+ * the whole map */
+__device__ __forceinline__ bool in_active_area(const UpdArgs& a, const Surfel4& s, bool* in_tile) {
   float Ps[16];
   load_pose(a.poses, (int32_t)s.c.w, Ps);
   v3 pos = m4_point(Ps, xyz(s.a));
+  *in_tile = !(sdm_abs(pos.x - a.ex_cx) > a.ex_extent || sdm_abs(pos.y - a.ex_cy) > a.ex_extent);
   if ((int32_t)__float_as_uint(s.c.x) < 0) return false;
   if (sdm_abs(pos.x - a.cx) > a.extent || sdm_abs(pos.y - a.cy) > a.extent) return false;
   return true;
@@ -492,6 +498,7 @@ extern "C" int suma_debug_k9_phases(unsigned long long* host, int reset) {
 __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
   __shared__ float4 s_out[2][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
   __shared__ uint16_t s_slot[2][SUMA_TILE]; /* stable rank -> slot */
+  __shared__ uint8_t s_ext[2][SUMA_TILE];   /* slot -> "in the tile that is extracted after this update" */
   __shared__ uint32_t s_cnt_emit[K9_PER][K9_WAVES], s_cnt_keep[K9_WAVES];
   __shared__ uint32_t s_tile, s_prefix;
   const uint32_t S = a.ds->n_surfels;
@@ -542,8 +549,10 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
         int32_t mark_pix;
         const bool keep = k9_finish(a, idx[u], in[u], pre[u], rec[u], o, &mark_pix) && live[u];
         if (keep && mark_pix >= 0) a.integrated[mark_pix] = 1;
-        emit[u] = keep && in_active_area(a, o);
+        bool in_tile;
+        emit[u] = in_active_area(a, o, &in_tile) && keep;
         const uint32_t slot = (uint32_t)u * K9_THREADS + threadIdx.x;
+        s_ext[buf][slot] = in_tile ? 1 : 0;
         s_out[buf][slot][0] = o.a;
         s_out[buf][slot][1] = o.b;
         s_out[buf][slot][2] = o.c;
@@ -595,7 +604,11 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
       /* compacted stream-out: chunk c = (rank, 16-byte part) */
       for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
         const uint64_t d = 4ull * prefix + c;
-        if (d < 4ull * a.max_surfels) store_stream(&dst4[d], s_out[pb][s_slot[pb][c >> 2]][c & 3u]);
+        if (d < 4ull * a.max_surfels) {
+          const uint32_t slot = s_slot[pb][c >> 2];
+          store_stream(&dst4[d], s_out[pb][slot][c & 3u]);
+          if (a.ex_flags != nullptr && (c & 3u) == 0) a.ex_flags[d >> 2] = s_ext[pb][slot];
+        }
       }
       if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
         const uint32_t tot = prefix + prev_total;
@@ -655,7 +668,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
       q = threadIdx.x;
     }
     const uint32_t t = tile * SUMA_TILE + q; /* x-major item index */
-    bool gen = false, emit = false;
+    bool gen = false, emit = false, in_tile = false;
     Surfel4 s;
     if (t < P) {
       const int32_t x = (int32_t)(t / (uint32_t)H), y = (int32_t)(t % (uint32_t)H);
@@ -680,7 +693,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
         s.b = f4(ng.x, ng.y, ng.z, conf);
         s.c = f4(__uint_as_float((uint32_t)a.timestamp), color, 1.0f, (float)a.timestamp);
         s.d = sem;
-        emit = in_active_area(a, s);
+        emit = in_active_area(a, s, &in_tile);
       }
     }
     {
@@ -701,7 +714,10 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     __syncthreads();
     if (emit) {
       uint64_t dst = (uint64_t)base + s_prefix + s_rank[q];
-      if (dst < a.max_surfels) store_surfel(a.out, (uint32_t)dst, s);
+      if (dst < a.max_surfels) {
+        store_surfel(a.out, (uint32_t)dst, s);
+        if (a.ex_flags != nullptr) a.ex_flags[dst] = in_tile ? 1 : 0;
+      }
     }
     if (tile == ntiles - 1 && threadIdx.x == 0) {
       uint64_t kept = (uint64_t)s_prefix + br.total;
@@ -751,7 +767,7 @@ K8Out launch_k8_out(suma_ctx* c) {
 /* K7..K11 of SurfelMap::update for the current map (c->surfels[c->cur]); the result lands in the
  * other buffer, which the caller makes current. */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent, int k7_done) {
+                             float cy, float extent, int k7_done, const float* ex) {
   const uint32_t P = (uint32_t)c->P;
   const double S = (double)c->known_surfels;
   UpdArgs a;
@@ -798,6 +814,10 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.cx = cx;
   a.cy = cy;
   a.extent = extent;
+  a.ex_flags = ex ? c->extract_flags : nullptr;
+  a.ex_cx = ex ? ex[0] : 0.0f;
+  a.ex_cy = ex ? ex[1] : 0.0f;
+  a.ex_extent = ex ? ex[2] : 0.0f;
   hipStream_t st = c->ls;
   const uint32_t gridS = stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
   a.pose_idx = c->timestamp;
@@ -893,6 +913,7 @@ struct ExtractArgs {
   uint32_t group_words;
   uint32_t epoch, slot, arena_cap;
   float cx, cy, extent;
+  const uint8_t* flags; /* selection bytes of the update that has just run (K9 / K10 / k_append_cached), or NULL */
 };
 
 /* extract_surfels.vert:46-64: stable compaction of the surfels of one submap tile into the
@@ -901,6 +922,10 @@ struct ExtractArgs {
  * of its loads in flight at once, decides from position + creation stamp only, and re-reads the few
  * selected records when their output offset is known. */
 #define K12_ITEMS 4u
+/* FLAGS: the selection was made by the update that has just run (one byte per surfel at its final index, written by
+ * K9 / K10 and, for tiles re-appended from the cache, by k_append_cached): one byte per surfel is read instead of
+ * position + creation stamp + pose entry */
+template <bool FLAGS>
 __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
   __shared__ uint32_t s_tile, s_prefix;
   __shared__ uint32_t s_cnt[K12_ITEMS][TILE_WAVES];
@@ -919,14 +944,20 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
     if (tile >= ntiles) break;
     float4 pa[K12_ITEMS];
     float cnt[K12_ITEMS];
+    uint32_t fl[K12_ITEMS];
 #pragma unroll
     for (uint32_t k = 0; k < K12_ITEMS; ++k) { /* all loads first */
       const uint32_t i = tile * span + k * SUMA_TILE + threadIdx.x;
       pa[k] = f4(0.f, 0.f, 0.f, 0.f);
       cnt[k] = 0.f;
+      fl[k] = 0;
       if (i < S) {
-        pa[k] = sf[4 * (size_t)i];
-        cnt[k] = sf[4 * (size_t)i + 2].w;
+        if (FLAGS) {
+          fl[k] = a.flags[i];
+        } else {
+          pa[k] = sf[4 * (size_t)i];
+          cnt[k] = sf[4 * (size_t)i + 2].w;
+        }
       }
     }
     bool sel[K12_ITEMS];
@@ -935,7 +966,9 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
     for (uint32_t k = 0; k < K12_ITEMS; ++k) {
       const uint32_t i = tile * span + k * SUMA_TILE + threadIdx.x;
       sel[k] = false;
-      if (i < S) {
+      if (FLAGS) {
+        sel[k] = fl[k] != 0; /* 0 beyond S */
+      } else if (i < S) {
         float Ps[16];
         load_pose(a.poses, (int32_t)cnt[k], Ps);
         v3 pos = m4_point(Ps, xyz(pa[k]));
@@ -970,7 +1003,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
         const uint32_t dst = s_prefix + rank[k];
         if (dst < SUMA_EXTRACT_CAPACITY && (uint64_t)base + dst < a.arena_cap) {
           Surfel4 s;
-          s.a = pa[k];
+          s.a = FLAGS ? sf[4 * (size_t)i] : pa[k];
           s.b = sf[4 * (size_t)i + 1];
           s.c = sf[4 * (size_t)i + 2];
           s.d = sf[4 * (size_t)i + 3];
@@ -1000,8 +1033,9 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
   }
 }
 
-hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent) {
+hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent, int use_flags) {
   ExtractArgs a;
+  a.flags = use_flags ? c->extract_flags : nullptr;
   a.in = c->surfels[c->cur];
   a.arena = c->cache_arena;
   a.ds = c->ds;
@@ -1017,15 +1051,23 @@ hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float 
   a.cx = cx;
   a.cy = cy;
   a.extent = extent;
-  ProfScope ps(c, "k12_extract_submap", 64.0 * (double)c->known_surfels);
-  k12_extract<<<compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + K12_ITEMS - 1) / K12_ITEMS), SUMA_TILE, 0, c->ls>>>(a);
+  /* algorithmic bytes (K12 reads the map it filters): 64 S without the selection bytes, S with them */
+  ProfScope ps(c, "k12_extract_submap", (use_flags ? 1.0 : 64.0) * (double)c->known_surfels);
+  const uint32_t grid = compact_grid(c, ((uint64_t)c->known_surfels + 2 * c->P + K12_ITEMS - 1) / K12_ITEMS);
+  if (use_flags)
+    k12_extract<true><<<grid, SUMA_TILE, 0, c->ls>>>(a);
+  else
+    k12_extract<false><<<grid, SUMA_TILE, 0, c->ls>>>(a);
   return hipGetLastError();
 }
 
-/* append the cached surfels of one tile to the active map (SurfelMap.cpp:775-780, 801-806) */
+/* append the cached surfels of one tile to the active map (SurfelMap.cpp:775-780, 801-806); when the update has
+ * flagged a tile for extraction, the appended records get their selection byte here (the K12 predicate,
+ * extract_surfels.vert:46-64), so that K12 can rely on the bytes for the whole map */
 __global__ void __launch_bounds__(256)
     k_append_cached(suma_surfel* surfels, const suma_surfel* arena, DevState* ds, const CacheSlot* slots,
-                    uint32_t slot, uint32_t max_surfels) {
+                    uint32_t slot, uint32_t max_surfels, const float* poses, uint8_t* ex_flags, float ex_cx, float ex_cy,
+                    float ex_extent) {
   const CacheSlot cs = slots[slot];
   const uint32_t S = ds->n_surfels;
   const float4* __restrict__ src = reinterpret_cast<const float4*>(arena + cs.offset);
@@ -1034,6 +1076,14 @@ __global__ void __launch_bounds__(256)
   if ((uint64_t)S + n > max_surfels) n = max_surfels - S;
   for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < 4ull * n; k += (uint64_t)gridDim.x * blockDim.x)
     dst[4ull * S + k] = src[k];
+  if (ex_flags != nullptr)
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x) {
+      const float4 pa = src[4 * k];
+      float Ps[16];
+      load_pose(poses, (int32_t)src[4 * k + 2].w, Ps);
+      const v3 pos = m4_point(Ps, xyz(pa));
+      ex_flags[S + k] = !(sdm_abs(pos.x - ex_cx) > ex_extent || sdm_abs(pos.y - ex_cy) > ex_extent) ? 1 : 0;
+    }
 }
 __global__ void k_append_commit(DevState* ds, const CacheSlot* slots, uint32_t slot, uint32_t max_surfels) {
   uint32_t S = ds->n_surfels, n = slots[slot].count;
@@ -1045,8 +1095,15 @@ __global__ void k_append_commit(DevState* ds, const CacheSlot* slots, uint32_t s
 }
 
 hipError_t launch_append_cached(suma_ctx* c, uint32_t slot) {
+  float ex[3] = {0.f, 0.f, 0.f};
+  if (c->flagged.valid) {
+    ex[0] = (float)(2.0 * c->flagged.i * c->p.submap_extent); /* submapIndex2center, SurfelMap.cpp:704-706 */
+    ex[1] = (float)(2.0 * c->flagged.j * c->p.submap_extent);
+    ex[2] = c->p.submap_extent;
+  }
   k_append_cached<<<1024, 256, 0, c->ls>>>(c->surfels[c->cur], c->cache_arena, c->ds, c->cache_slots, slot,
-                                               c->p.max_surfels);
+                                               c->p.max_surfels, c->poses, c->flagged.valid ? c->extract_flags : nullptr,
+                                               ex[0], ex[1], ex[2]);
   k_append_commit<<<1, 1, 0, c->ls>>>(c->ds, c->cache_slots, slot, c->p.max_surfels);
   return hipGetLastError();
 }

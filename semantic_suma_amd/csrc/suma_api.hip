@@ -294,6 +294,8 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->pixrec, P * 4 * sizeof(float4)));
     CK(hipMalloc((void**)&c->integrated, P));
     CK(hipMemsetAsync(c->integrated, 0, P, c->stream));
+    CK(hipMalloc((void**)&c->extract_flags, (size_t)params->max_surfels));
+    c->flagged.valid = false;
     CK(hipMalloc((void**)&c->index_map, P * 4));
     CK(hipMemsetAsync(c->index_map, 0, P * 4, c->stream));
     CK(hipMalloc((void**)&c->zbuf_a, Pm * 8));
@@ -377,7 +379,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.b);
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
-  void* dev[] = {c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
+  void* dev[] = {c->extract_flags, c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
                  c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs, c->sync_flags, c->zbuf_k1,
@@ -750,7 +752,11 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     uint32_t slot;
     int r = cache_slot_for(c, idx.first, idx.second, &slot);
     if (r) return r;
-    CK(launch_extract(c, slot, cx, cy, c->p.submap_extent));
+    /* K9 / K10 of the update that has just run flagged the surfels of this very tile at their final index
+     * (peek_extraction): the extraction reads one byte per surfel instead of position + creation stamp of the whole map */
+    const int use_flags = (c->flagged.valid && c->flagged.i == idx.first && c->flagged.j == idx.second) ? 1 : 0;
+    c->flagged.valid = false;
+    CK(launch_extract(c, slot, cx, cy, c->p.submap_extent, use_flags));
     if (partially) break;
   }
   return SUMA_OK;
@@ -761,6 +767,35 @@ static int append_cached(suma_ctx* c, int32_t i, int32_t j) {
   if (it == c->cache_index.end()) return SUMA_OK; /* never extracted: an empty SubmapCache */
   CK(launch_append_cached(c, it->second));
   return SUMA_OK;
+}
+
+/* The tile updateActiveSubmaps -> extractSurfels(partially = true) will extract right after the update at `pose`
+ * (SurfelMap.cpp:744-824, 708-742): the same decisions on a copy of the state.  false: none, or not exactly one. */
+static bool peek_extraction(const suma_ctx* c, const float* pose, int32_t* ti, int32_t* tj) {
+  if (!c->p.partial_extraction || getenv("SUMA_NO_EXTRACT_FLAGS")) return false; /* all pending tiles in one go: no single tile to flag */
+  const int32_t dim = c->p.submap_dimension;
+  const float ext = c->p.submap_extent;
+  int32_t oi = c->origin_i, oj = c->origin_j;
+  float cx, cy;
+  submap_center(c, oi, oj, &cx, &cy);
+  const float changex = pose[12] - cx, changey = pose[13] - cy, factor = 1.1f;
+  bool have = !c->extraction.empty();
+  std::pair<int32_t, int32_t> last = have ? c->extraction.back() : std::make_pair(0, 0);
+  if (fabsf(changex) > factor * ext) {
+    const int32_t dir = (changex < 0) ? -1 : 1;
+    last = {oi - dir * dim, oj + dim}; /* the last tile of the pushed row, k = dim */
+    have = true;
+    oi += dir;
+  }
+  if (fabsf(changey) > factor * ext) {
+    const int32_t dir = (changey < 0) ? -1 : 1;
+    last = {oi + dim, oj - dir * dim};
+    have = true;
+  }
+  if (!have) return false;
+  *ti = last.first;
+  *tj = last.second;
+  return true;
 }
 
 /* SurfelMap::updateActiveSubmaps, SurfelMap.cpp:744-824 */
@@ -817,7 +852,17 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
     if (!k7_done) CK(launch_clear_index_zbuf(c)); /* different pose after all (fallback ICP): redo K7 */
     c->k7.valid = false;
   }
-  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done));
+  float ex[3];
+  int32_t ti = 0, tj = 0;
+  const bool flag_tile = peek_extraction(c, pose, &ti, &tj);
+  if (flag_tile) {
+    submap_center(c, ti, tj, &ex[0], &ex[1]);
+    ex[2] = c->p.submap_extent;
+  }
+  c->flagged.valid = flag_tile;
+  c->flagged.i = ti;
+  c->flagged.j = tj;
+  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done, flag_tile ? ex : nullptr));
   c->cur ^= 1;
   c->map_version++;
   int r = update_active_submaps(c, pose);

@@ -163,6 +163,13 @@ struct suma_ctx {
   float4* radius_conf;                 /* P */
   float4* pixrec;                      /* P x 4: packed measurement record for K9 (one 64-byte line per pixel) */
   uint8_t* integrated;                 /* P */
+  /* one byte per surfel of the compaction target: "lies in the submap tile that is extracted right after this update"
+   * (written by K9 / K10 at the surfel's final index, read by K12 instead of a pass over the whole map) */
+  uint8_t* extract_flags;              /* max_surfels */
+  struct {
+    bool valid;                        /* the last update flagged the tile (i, j) */
+    int32_t i, j;
+  } flagged;
   uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
   unsigned long long* tile_status;     /* look-back status words */
   unsigned long long* tile_group;      /* 2 x group_words, per 64 tiles: {arrived, sum}; launches alternate halves */
@@ -292,13 +299,14 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
 hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
                                       float conf_threshold);
 /* k_update.hip */
+/* ex: optional centre (x, y) + half-width of the submap tile that will be extracted right after this update */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent, int k7_done);
+                             float cy, float extent, int k7_done, const float* ex);
 hipError_t launch_clear_index_zbuf(suma_ctx* c);
 K8Out launch_k8_out(suma_ctx* c);
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);
 hipError_t launch_fill_identity_poses(suma_ctx* c);
-hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent);
+hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent, int use_flags);
 hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
 
 /* k_sync.hip: in-memory hand-offs between the ctx stream and the side stream.  A runtime event dependency between two
