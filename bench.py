@@ -218,7 +218,7 @@ def main():
                          "the reference's own alternative 4096 * 4096)")
     ap.add_argument("--adapter-scans", type=int, default=120,
                     help="scans of the class-by-class adapter path timing (tools/adapter_bench.cpp; 0 = skip)")
-    ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11"],
+    ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11", "adapter"],
                     help="single: BASELINE configs[1] (the bench contract); hypotheses: configs[2], 8 ICP hypotheses per scan "
                          "sharded over the ranks; sequences11: configs[3], the 11 KITTI sequence lengths (scaled) LPT-assigned")
     ap.add_argument("--kernels-json", default=os.path.join(ROOT, "gpurun_out", "bench_kernels.json"))
@@ -249,6 +249,11 @@ def main():
     from semantic_suma_amd.types import params_with_size
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
+    if args.mode == "adapter":  # only the host-language comparison of tools/adapter_bench.cpp (no torch.distributed)
+        n = max(10, args.adapter_scans)
+        print(json.dumps(adapter_path([(None, None, None, 0, cached_scan(k, W, H)) for k in range(n)], W, H,
+                                      args.icp_iterations)))
+        return
     if args.mode != "single":
         run_other_mode(args, rank, local_rank, world, coll_dev)
         if world > 1:

@@ -53,6 +53,7 @@ struct IngestSlot {
 /* The blocking host-pointer entry copies a scan (~3 MB) into pinned memory on the CALLER's time line: one core moves
  * that in ~250 us, about a whole scan's worth of GPU time.  A few helper threads that sleep on a condition variable
  * between scans take a share each. */
+#define HOST_CHUNKS 4 /* pieces of a host scan whose pinned copy and DMA are pipelined (blocking entry) */
 #define COPY_HELPERS 3
 #define COPY_SEGMENTS 3 /* points, labels, probs */
 struct CopySeg {
@@ -404,8 +405,32 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
       segs[nseg++] = {q->pinned + probs_offset(n), (const char*)probs, (size_t)n * sizeof(float)};
       bytes = probs_offset(n) + (size_t)n * sizeof(float);
     }
-    pool_copy(&g->pool, segs, nseg);
-    HIP_TRY(c, hipMemcpyAsync(q->device, q->pinned, bytes, hipMemcpyHostToDevice, g->copy_stream));
+    /* The pinned copy and the PCIe transfer are pipelined in HOST_CHUNKS pieces: the DMA of piece k runs while the
+     * caller and the helpers copy piece k + 1, so the scan is on the device ~one piece after the last byte has been
+     * copied (one copy + one transfer back to back took about as long as the GPU work queued behind the previous
+     * call, and the preprocessing waited for the rest) */
+    (void)segs;
+    (void)nseg;
+    const size_t piece = ((bytes / HOST_CHUNKS) + 4095) & ~(size_t)4095;
+    /* the staging layout is points | labels | probs at fixed offsets: walk it piece by piece, copying from whichever
+     * source arrays overlap the piece */
+    const size_t off_l = labels_offset(n), off_p = probs_offset(n);
+    const struct { size_t off, len; const char* src; } part[3] = {
+        {0, (size_t)n * sizeof(float4), (const char*)points},
+        {off_l, labels ? (size_t)n * sizeof(float) : 0, (const char*)labels},
+        {off_p, probs ? (size_t)n * sizeof(float) : 0, (const char*)probs}};
+    for (size_t lo = 0; lo < bytes; lo += piece) {
+      const size_t hi = lo + piece < bytes ? lo + piece : bytes;
+      CopySeg ps[COPY_SEGMENTS];
+      int np = 0;
+      for (int k = 0; k < 3; ++k) {
+        const size_t a = part[k].off > lo ? part[k].off : lo;
+        const size_t b = (part[k].off + part[k].len) < hi ? (part[k].off + part[k].len) : hi;
+        if (part[k].len && a < b) ps[np++] = {q->pinned + a, part[k].src + (a - part[k].off), b - a};
+      }
+      pool_copy(&g->pool, ps, np);
+      HIP_TRY(c, hipMemcpyAsync(q->device + lo, q->pinned + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream));
+    }
   }
   HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
   r = pipeline_begin_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,

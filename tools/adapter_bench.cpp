@@ -136,10 +136,40 @@ static double run_classes(const suma_params& p0, const std::vector<Scan>& scans,
   return dt;
 }
 
-static double run_pipeline(const suma_params& p, const std::vector<Scan>& scans, int gn_iterations, bool phases,
+/* mode 0: one call per scan from host vectors; 1: the phase calls with empty loop-closure hooks; 2: scans resident
+ * in HBM beforehand (suma_pipeline_process_scan_device) -- the rate the host-vector entries are measured against */
+static double run_pipeline(const suma_params& p, const std::vector<Scan>& scans, int gn_iterations, int mode,
                            double* end_pose) {
   suma_hip::SurfelMapping sm(p, 0);
   auto nop = [](suma_hip::SurfelMapping&) {};
+  const bool phases = mode == 1;
+  std::vector<void*> dev;
+  if (mode == 2) {
+    for (const Scan& sc : scans) {
+      void *dp = nullptr, *dl = nullptr, *dq = nullptr;
+      const size_t n = sc.pts.size();
+      suma_hip::check(sm.ctx(), suma_device_alloc(sm.ctx(), n * sizeof(suma_float4), &dp), "alloc");
+      suma_hip::check(sm.ctx(), suma_device_alloc(sm.ctx(), n * sizeof(float), &dl), "alloc");
+      suma_hip::check(sm.ctx(), suma_device_alloc(sm.ctx(), n * sizeof(float), &dq), "alloc");
+      suma_device_upload(sm.ctx(), dp, sc.pts.data(), n * sizeof(suma_float4));
+      suma_device_upload(sm.ctx(), dl, sc.lab.data(), n * sizeof(float));
+      suma_device_upload(sm.ctx(), dq, sc.prob.data(), n * sizeof(float));
+      dev.push_back(dp);
+      dev.push_back(dl);
+      dev.push_back(dq);
+    }
+    suma_synchronize(sm.ctx());
+    const double t0 = now();
+    for (size_t k = 0; k < scans.size(); ++k)
+      suma_hip::check(sm.ctx(), suma_pipeline_process_scan_device(sm.get(), (const suma_float4*)dev[3 * k], (const float*)dev[3 * k + 1],
+                                                                   (const float*)dev[3 * k + 2], (uint32_t)scans[k].pts.size(),
+                                                                   gn_iterations), "process_scan_device");
+    suma_synchronize(sm.ctx());
+    const double dt = now() - t0;
+    sm.getCurrentPose(end_pose);
+    for (void* d : dev) suma_device_free(sm.ctx(), d);
+    return dt;
+  }
   const double t0 = now();
   for (const Scan& sc : scans) {
     if (phases)
@@ -182,16 +212,20 @@ int main(int argc, char** argv) {
     /* a short run of each first (module load, first-touch allocations), then the timed runs */
     std::vector<Scan> head(scans.begin(), scans.begin() + (n_scans < 5 ? n_scans : 5));
     run_classes(p, head, gn_iterations, pc);
-    run_pipeline(p, head, gn_iterations, true, pp);
+    run_pipeline(p, head, gn_iterations, 1, pp);
+    double pr[16];
     const double t_classes = run_classes(p, scans, gn_iterations, pc);
-    const double t_phases = run_pipeline(p, scans, gn_iterations, true, pp);
-    const double t_pipeline = run_pipeline(p, scans, gn_iterations, false, pl);
+    const double t_phases = run_pipeline(p, scans, gn_iterations, 1, pp);
+    const double t_pipeline = run_pipeline(p, scans, gn_iterations, 0, pl);
+    const double t_resident = run_pipeline(p, scans, gn_iterations, 2, pr);
     bool same = true;
-    for (int i = 0; i < 16; ++i) same = same && pc[i] == pp[i] && pp[i] == pl[i];
+    for (int i = 0; i < 16; ++i) same = same && pc[i] == pp[i] && pp[i] == pl[i] && pl[i] == pr[i];
     std::printf("{\"scans\": %d, \"classes_scans_per_s\": %.1f, \"phases_scans_per_s\": %.1f, \"pipeline_scans_per_s\": %.1f, "
-                "\"end_pose_bits_equal\": %s, \"input\": \"host vectors (pageable), %ux%u, %d GN iterations\"}\n",
-                n_scans, n_scans / t_classes, n_scans / t_phases, n_scans / t_pipeline, same ? "true" : "false",
-                p.data_width, p.data_height, gn_iterations);
+                "\"resident_scans_per_s\": %.1f, \"host_vectors_vs_resident\": %.3f, "
+                "\"end_pose_bits_equal\": %s, \"input\": \"host vectors (pageable) unless resident, %ux%u, %d GN iterations, the "
+                "first %d scans of the sequence (growing map)\"}\n",
+                n_scans, n_scans / t_classes, n_scans / t_phases, n_scans / t_pipeline, n_scans / t_resident,
+                t_resident / t_pipeline, same ? "true" : "false", p.data_width, p.data_height, gn_iterations, n_scans);
   } catch (const std::exception& e) {
     std::fprintf(stderr, "adapter_bench: %s\n", e.what());
     return 1;
