@@ -28,22 +28,6 @@ __global__ void k_gate(const uint32_t* word, uint32_t seq, uint32_t* fault) {
   atomicOr(fault, 8u);
 }
 
-/* the same gate on a word in pinned HOST memory that a host thread stores to (system scope): the copy stream of the
- * scan ingest waits here until the host-side copy into the pinned staging block has finished, so that the caller can
- * enqueue the transfer and everything behind it while its helper threads are still copying (suma_ingest.hip) */
-__global__ void k_gate_host(const uint32_t* word, uint32_t seq, uint32_t* fault) {
-  if (threadIdx.x != 0) return;
-  for (uint32_t spins = 0; spins < (1u << 22); ++spins) {
-    if ((int32_t)(__hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - seq) >= 0) return;
-    __builtin_amdgcn_s_sleep(64);
-  }
-  atomicOr(fault, 8u);
-}
-hipError_t launch_gate_host(suma_ctx* c, hipStream_t st, const uint32_t* d_word, uint32_t seq) {
-  k_gate_host<<<1, 64, 0, st>>>(d_word, seq, &c->ds->overflow);
-  return hipGetLastError();
-}
-
 hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq) {
   k_signal<<<1, 1, 0, st>>>(c->sync_flags + word, seq);
   return hipGetLastError();

@@ -53,6 +53,7 @@ struct IngestSlot {
 /* The blocking host-pointer entry copies a scan (~3 MB) into pinned memory on the CALLER's time line: one core moves
  * that in ~250 us, about a whole scan's worth of GPU time.  A few helper threads that sleep on a condition variable
  * between scans take a share each. */
+#define HOST_CHUNKS 4 /* pieces of a host scan whose pinned copy and DMA are pipelined (blocking entry) */
 #define COPY_HELPERS 7
 #define COPY_SEGMENTS 3 /* points, labels, probs */
 struct CopySeg {
@@ -69,10 +70,6 @@ struct CopyPool {
   uint64_t posted;
   int pending;
   bool stop;
-  /* asynchronous jobs (pool_post): the helper that finishes last stores done_value to done_flag (pinned host word a
-   * gate kernel on the copy stream polls, k_sync.hip) */
-  volatile uint32_t* done_flag;
-  uint32_t done_value;
 };
 
 static void copy_helper(CopyPool* p, int id) {
@@ -91,10 +88,6 @@ static void copy_helper(CopyPool* p, int id) {
     {
       std::lock_guard<std::mutex> lk(p->mu);
       p->pending -= 1;
-      if (p->pending == 0 && p->done_flag) {
-        __atomic_store_n(p->done_flag, p->done_value, __ATOMIC_RELEASE); /* the copies above are complete */
-        p->done_flag = nullptr;
-      }
     }
     p->done_cv.notify_one();
   }
@@ -108,36 +101,6 @@ static CopySeg seg_share(const CopySeg& s, int part) {
   if (s.bytes == 0 || lo >= s.bytes) return {nullptr, nullptr, 0};
   const size_t n = (part == (int)parts - 1 || lo + share > s.bytes) ? s.bytes - lo : share;
   return {s.dst + lo, s.src + lo, n};
-}
-
-/* share `part` of a segment split into `parts` page-aligned shares */
-static CopySeg seg_share_n(const CopySeg& s, int part, int parts) {
-  const size_t share = ((s.bytes / (size_t)parts) + 4095) & ~(size_t)4095;
-  const size_t lo = share * (size_t)part;
-  if (s.bytes == 0 || lo >= s.bytes) return {nullptr, nullptr, 0};
-  const size_t n = (part == parts - 1 || lo + share > s.bytes) ? s.bytes - lo : share;
-  return {s.dst + lo, s.src + lo, n};
-}
-/* every segment dst <- src by the helpers ALONE; returns at once.  When all shares are done the last helper stores
- * `value` to `flag`; pool_wait blocks until then. */
-static void pool_post(CopyPool* p, const CopySeg* segs, int nseg, volatile uint32_t* flag, uint32_t value) {
-  {
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->posted += 1;
-    p->pending = COPY_HELPERS;
-    p->done_flag = flag;
-    p->done_value = value;
-    for (int h = 0; h < COPY_HELPERS; ++h) {
-      for (int k = 0; k < COPY_SEGMENTS; ++k)
-        p->job[h][k] = (k < nseg) ? seg_share_n(segs[k], h, COPY_HELPERS) : CopySeg{nullptr, nullptr, 0};
-      p->gen[h] = p->posted;
-    }
-  }
-  p->cv.notify_all();
-}
-static void pool_wait(CopyPool* p) {
-  std::unique_lock<std::mutex> lk(p->mu);
-  p->done_cv.wait(lk, [&] { return p->pending == 0; });
 }
 
 /* every segment dst <- src, split over the helpers and the calling thread; one wake-up for the whole scan */
@@ -174,9 +137,6 @@ struct Ingest {
   /* blocking entry (suma_pipeline_process_scan): two staging slots of its own, used alternately */
   IngestSlot bslot[2];
   uint32_t bnext;
-  uint32_t* h_copied;       /* pinned host word: sequence number of the last host copy that has completed */
-  const uint32_t* d_copied; /* its device address */
-  uint32_t copy_seq;
   CopyPool pool;
   uint32_t head, tail; /* next slot to process / next slot to fill (counts, slot = count % INGEST_SLOTS) */
   std::mutex mu;
@@ -265,23 +225,11 @@ static int ingest_get(suma_pipeline* s, Ingest** out) {
   }
   for (auto& q : g->bslot) memset(&q, 0, sizeof(q));
   g->bnext = 0;
-  g->h_copied = nullptr;
-  g->d_copied = nullptr;
-  g->copy_seq = 0;
-  g->pool.done_flag = nullptr;
-  g->pool.done_value = 0;
   g->pool.posted = 0;
   g->pool.pending = 0;
   g->pool.stop = false;
   for (int h = 0; h < COPY_HELPERS; ++h) g->pool.gen[h] = 0;
   HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
-  HIP_TRY(c, hipHostMalloc((void**)&g->h_copied, 64, hipHostMallocMapped));
-  *g->h_copied = 0;
-  {
-    void* d = nullptr;
-    HIP_TRY(c, hipHostGetDevicePointer(&d, g->h_copied, 0));
-    g->d_copied = (const uint32_t*)d;
-  }
   for (auto& q : g->slot) {
     HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
@@ -327,7 +275,6 @@ void ingest_destroy(suma_pipeline* s) {
     if (q.consumed) hipEventDestroy(q.consumed);
   }
   hipStreamDestroy(g->copy_stream);
-  if (g->h_copied) hipHostFree(g->h_copied);
   delete g;
   s->ingest = nullptr;
 }
@@ -445,8 +392,6 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
   IngestSlot* q = &g->bslot[g->bnext++ & 1u];
   if (q->consumed_valid) HIP_TRY(c, hipEventSynchronize(q->consumed)); /* the scan before last has read this slot */
   HIP_TRY(c, slot_reserve(g, q, n));
-  bool posted = false;
-  size_t upload_bytes = 0;
   if (n > 0) {
     CopySeg segs[COPY_SEGMENTS];
     int nseg = 0;
@@ -460,37 +405,41 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
       segs[nseg++] = {q->pinned + probs_offset(n), (const char*)probs, (size_t)n * sizeof(float)};
       bytes = probs_offset(n) + (size_t)n * sizeof(float);
     }
-    /* The helpers copy the scan into the pinned block while THIS thread already enqueues the transfer and the whole
-     * scan behind it: the copy stream first runs a gate that polls a pinned host word, which the helper that finishes
-     * last stores to (k_gate_host).  The ~3 MB copy (tens of microseconds on eight cores) thus costs the caller no
-     * time before its first launch; it is joined before the call returns (the caller may then reuse its arrays). */
-    if (bytes >= (256u << 10) && !g->pool.th.empty()) {
-      g->copy_seq += 1;
-      pool_post(&g->pool, segs, nseg, g->h_copied, g->copy_seq);
-      posted = true;
-    } else {
-      for (int k = 0; k < nseg; ++k)
-        if (segs[k].bytes) memcpy(segs[k].dst, segs[k].src, segs[k].bytes);
+    /* The pinned copy and the PCIe transfer are pipelined in HOST_CHUNKS pieces: the DMA of piece k runs while the
+     * caller and the helpers copy piece k + 1, so the scan is on the device ~one piece after the last byte has been
+     * copied (one copy + one transfer back to back took about as long as the GPU work queued behind the previous
+     * call, and the preprocessing waited for the rest) */
+    (void)segs;
+    (void)nseg;
+    const size_t piece = ((bytes / HOST_CHUNKS) + 4095) & ~(size_t)4095;
+    /* the staging layout is points | labels | probs at fixed offsets: walk it piece by piece, copying from whichever
+     * source arrays overlap the piece */
+    const size_t off_l = labels_offset(n), off_p = probs_offset(n);
+    const struct { size_t off, len; const char* src; } part[3] = {
+        {0, (size_t)n * sizeof(float4), (const char*)points},
+        {off_l, labels ? (size_t)n * sizeof(float) : 0, (const char*)labels},
+        {off_p, probs ? (size_t)n * sizeof(float) : 0, (const char*)probs}};
+    for (size_t lo = 0; lo < bytes; lo += piece) {
+      const size_t hi = lo + piece < bytes ? lo + piece : bytes;
+      CopySeg ps[COPY_SEGMENTS];
+      int np = 0;
+      for (int k = 0; k < 3; ++k) {
+        const size_t a = part[k].off > lo ? part[k].off : lo;
+        const size_t b = (part[k].off + part[k].len) < hi ? (part[k].off + part[k].len) : hi;
+        if (part[k].len && a < b) ps[np++] = {q->pinned + a, part[k].src + (a - part[k].off), b - a};
+      }
+      pool_copy(&g->pool, ps, np);
+      HIP_TRY(c, hipMemcpyAsync(q->device + lo, q->pinned + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream));
     }
-    upload_bytes = bytes;
   }
-  /* from here on every exit joins the helpers first: they read the caller's arrays */
-  auto enqueue = [&]() -> int {
-    if (posted) HIP_TRY(c, launch_gate_host(c, g->copy_stream, g->d_copied, g->copy_seq));
-    if (upload_bytes) HIP_TRY(c, hipMemcpyAsync(q->device, q->pinned, upload_bytes, hipMemcpyHostToDevice, g->copy_stream));
-    HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
-    int rr = pipeline_begin_scan_impl(s, (const suma_float4*)q->device,
-                                      labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
-                                      probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, q->uploaded);
-    q->consumed_valid = (hipEventRecord(q->consumed, pipeline_input_stream(s)) == hipSuccess);
-    if (rr == SUMA_OK && !begin_only) {
-      rr = pipeline_update_pose_impl(s, fixed_iterations);
-      if (rr == SUMA_OK) rr = pipeline_update_map_impl(s);
-    }
-    return rr;
-  };
-  r = enqueue();
-  if (posted) pool_wait(&g->pool); /* the caller's arrays have been read (long since, when the scan's result is back) */
+  HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
+  r = pipeline_begin_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
+                               probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, q->uploaded);
+  q->consumed_valid = (hipEventRecord(q->consumed, pipeline_input_stream(s)) == hipSuccess);
+  if (r == SUMA_OK && !begin_only) {
+    r = pipeline_update_pose_impl(s, fixed_iterations);
+    if (r == SUMA_OK) r = pipeline_update_map_impl(s);
+  }
   if (r != SUMA_OK) s->phase = 0;
   return r;
 }

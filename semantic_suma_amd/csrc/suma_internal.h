@@ -314,8 +314,6 @@ hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
  * 10 us kernels on one stream); a one-wave gate kernel that polls a sequence word costs ~2 us. */
 hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
 hipError_t launch_gate(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq);
-/* gate on a word in pinned host memory (device address d_word) that a host thread stores to */
-hipError_t launch_gate_host(suma_ctx* c, hipStream_t st, const uint32_t* d_word, uint32_t seq);
 /* makes the ctx stream wait for the pending preprocessing hand-off (one-wave gate kernel) */
 hipError_t flush_gate(suma_ctx* c);
 
