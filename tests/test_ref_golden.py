@@ -1,5 +1,5 @@
-"""Golden vectors produced by the reference's OWN shaders (tests/golden/ref_180x16.npz, made by
-tests/golden/make_ref_golden.py from oracle/_ref = the GLSL of /root/reference/src/shader compiled with g++; no oracle
+"""Golden vectors produced by the reference's OWN shaders (tests/golden/ref_180x16.npz and, at the bench geometry of
+BASELINE configs[1], tests/golden/ref_2048x64.npz; made by tests/golden/make_ref_golden.py from oracle/_ref = the GLSL of /root/reference/src/shader compiled with g++; no oracle
 code involved).  CPU: the oracle reproduces them.  GPU (-m gpu): the HIP path reproduces them through the C-ABI --
 a comparison of the product with the reference's shader arithmetic that does not pass through the oracle.
 Equal VALUES are demanded on every field (a shader transforms directions with a w = 0 column that adds a signed
@@ -15,9 +15,45 @@ import pytest
 
 from semantic_suma_amd.types import params_with_size
 
-G = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_180x16.npz"))
-W, H = int(G["W"]), int(G["H"])
-P = params_with_size(W, H, max_surfels=1 << 16, max_poses=64)
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Fixture:
+    """one file of reference-shader vectors.  180x16: inputs stored in the file.  2048x64 (the bench geometry, BASELINE
+    configs[1]): the inputs are the deterministic synthetic scans 0 and 2, regenerated here and checked against the
+    checksum the generator stored -- so the GPU leg at the bench size does not pass through the oracle either."""
+
+    def __init__(self, name, max_surfels):
+        self.G = np.load(os.path.join(HERE, "golden", name))
+        self.W, self.H = int(self.G["W"]), int(self.G["H"])
+        self.P = params_with_size(self.W, self.H, max_surfels=max_surfels, max_poses=64)
+        self._in = None
+
+    def inputs(self, k):
+        if "pts0" in self.G.files:
+            return self.G[f"pts{k}"], self.G[f"lab{k}"], self.G[f"prob{k}"]
+        if self._in is None:
+            import hashlib
+            from semantic_suma_amd import synth
+            s0 = synth.generate_scan(0, n_azimuth=self.W, height=self.H)[:3]
+            s1 = synth.generate_scan(2, n_azimuth=self.W, height=self.H)[:3]
+            h = hashlib.sha256(b"".join(np.ascontiguousarray(a).tobytes() for a in (*s0, *s1))).digest()
+            assert h == bytes(self.G["inputs_sha256"].tobytes()), "synthetic scans differ from the ones the fixture was made from"
+            self._in = (s0, s1)
+        return self._in[k]
+
+
+FIXTURES = {"180x16": ("ref_180x16.npz", 1 << 16), "2048x64": ("ref_2048x64.npz", 1 << 19)}
+_LOADED = {}
+
+
+def fixture(name):
+    if name not in _LOADED:
+        _LOADED[name] = Fixture(*FIXTURES[name])
+    return _LOADED[name]
+
+
+W, H = 180, 16  # the filter fixture below
 
 
 GF = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_filters_180x16.npz"))
@@ -51,9 +87,10 @@ def eq_map(got, want, nan, what):
         eq(a, b, f"{what}.{name}")
 
 
-def check(preprocess, update, k6):
+def check(fx, preprocess, update, k6):
     """preprocess(k, timestamp) -> (v, n, s); update(pose, k) -> (index_map, radius_conf, integrated, surfels);
     k6(T) -> acc words"""
+    G = fx.G
     for k in (0, 1):
         v, n, s = preprocess(k, k)
         eq(v, G[f"vertex{k}"], f"K1 vertex map {k}")
@@ -70,12 +107,14 @@ def check(preprocess, update, k6):
     assert G["map1"].shape[0] > 1500 and int(G["mask1"].sum()) > 200 and int(G["k6_acc"][29]) > 300
 
 
-def test_oracle_reproduces_reference_shader_vectors(oracle_lib):
-    ora = oracle_lib.Oracle(P)
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_oracle_reproduces_reference_shader_vectors(oracle_lib, name):
+    fx = fixture(name)
+    ora = oracle_lib.Oracle(fx.P, threads=4)
     frames = {}
 
     def preprocess(k, t):
-        f = ora.preprocess(G[f"pts{k}"], G[f"lab{k}"], G[f"prob{k}"], t, ora.frame())
+        f = ora.preprocess(*fx.inputs(k), t, ora.frame())
         frames[k] = f
         return f.vertex, f.normal, f.semantic
 
@@ -86,19 +125,22 @@ def test_oracle_reproduces_reference_shader_vectors(oracle_lib):
     def k6(T):
         return ora.jacobian_products(frames[1], frames[0], T, 0)[1]
 
-    check(preprocess, update, k6)
+    check(fx, preprocess, update, k6)
 
 
 @pytest.mark.gpu
-def test_hip_reproduces_reference_shader_vectors():
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_hip_reproduces_reference_shader_vectors(name):
     from semantic_suma_amd import core
-    ctx = core.Context(P)
+    fx = fixture(name)
+    ctx = core.Context(fx.P)
     pre, smap = core.Preprocessing(ctx), core.SurfelMap(ctx)
     frames = {}
 
     def preprocess(k, t):
-        f = core.Frame(ctx, W, H)
-        pre.process(G[f"pts{k}"], f, G[f"lab{k}"], G[f"prob{k}"], t)
+        f = core.Frame(ctx, fx.W, fx.H)
+        pts, lab, prob = fx.inputs(k)
+        pre.process(pts, f, lab, prob, t)
         frames[k] = f
         return f.download(0), f.download(1), f.download(2)
 
@@ -113,7 +155,7 @@ def test_hip_reproduces_reference_shader_vectors():
         obj.jacobianProducts()
         return obj.acc
 
-    check(preprocess, update, k6)
+    check(fx, preprocess, update, k6)
 
 
 def check_filters(name, preprocess):
