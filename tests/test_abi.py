@@ -130,3 +130,18 @@ def test_c_example_compiles_and_links(built, tmp_path):
                            os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "odometry.c"), "-o", str(exe),
                            "-L", libdir, "-lsuma_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
     assert subprocess.call([str(exe)], stderr=subprocess.DEVNULL) == 2
+
+
+def test_gl_interop_recipe_compiles_links_and_fails_cleanly(built, tmp_path):
+    """examples/gl_interop.cpp = the HIP -> GL hand-over of INTEGRATION.md 2a (hipGraphicsGLRegisterBuffer / Image, map,
+    device-to-device copy, unmap): compiles against the ROCm headers, links libamdhip64 + libsuma_hip, and -- there
+    being no GL context here -- reports the failed registration instead of crashing"""
+    exe = tmp_path / "gl_interop"
+    libdir = os.path.dirname(built.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "gl_interop.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lsuma_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "without a GL context: hipError" in out.stdout

@@ -104,3 +104,15 @@ def test_c_example_runs_on_kitti_style_files(hip, scan_dir, tmp_path):
         want = pipe.getCurrentPose()[:3, :].reshape(-1)
         got = np.array([float(v) for v in out[k].split()])
         assert np.allclose(got, want, rtol=0, atol=1e-8 * max(1.0, np.abs(want).max())), f"scan {k}"  # %.9g print
+
+
+def test_gl_interop_recipe_on_the_gpu_box(hip, tmp_path):
+    """the same program with a HIP device present and still no GL context: the registration is refused, nothing crashes"""
+    exe = os.path.join(str(tmp_path), "gl_interop")
+    libdir = os.path.dirname(hip.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-D__HIP_PLATFORM_AMD__", "-I", "/opt/rocm/include", "-I",
+                           os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "gl_interop.cpp"), "-o", exe, "-L",
+                           libdir, "-lsuma_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "without a GL context: hipError" in out.stdout, out.stdout + out.stderr
