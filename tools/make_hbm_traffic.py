@@ -18,7 +18,7 @@ def per_kernel(path, counter):
     by = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] == counter:
-            by[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+            by[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]].append(float(r["Counter_Value"]))
     return by
 
 

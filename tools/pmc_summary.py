@@ -9,7 +9,7 @@ import sys
 def main():
     by = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(sys.argv[1])):
-        by[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        by[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     names = sorted({c for k in by.values() for c in k})
     lines = [f"{'kernel':<28}{'n':>6}" + "".join(f"{c[:18]:>20}" for c in names)]
     for k, cs in sorted(by.items()):

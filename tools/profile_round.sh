@@ -1,25 +1,29 @@
 #!/bin/bash
-# One-call evidence run for profiles/ (inside a gpurun call, ~2 min of GPU time):
-#   gpurun --timeout 1800 -- 'bash tools/profile_round.sh r02'
-# writes gpurun_out/<tag>/: pytest, bench (default and 300 steps), rocprofv3 kernel trace + stats, the two HBM PMC
-# passes and three SQ-counter passes (counter runs WITHOUT any trace domain, as the pool requires), the
-# 50 M-surfel stress run, the config-3 / config-4 modes, the host-scan hand-over and the multi-pipeline run.  Afterwards, on the build machine:  bash tools/collect_profiles.sh <tag>
+# One-call evidence run for profiles/ (inside a gpurun call, ~12 min of GPU time):
+#   gpurun --timeout 2400 -- 'bash tools/profile_round.sh r03'
+# writes gpurun_out/<tag>/: pytest (incl. the 50 M-surfel case of BASELINE configs[4]), bench (default = timed at the
+# steady map after a 300-scan pre-roll, with the adapter-path and CPU legs), the literal full sequence (--steps 4541),
+# rocprofv3 kernel trace + stats, the two HBM PMC passes and three SQ-counter passes at the steady state (counter runs
+# WITHOUT any trace domain, as the pool requires), the 50 M-surfel stress run, the config-3 / config-4 modes, the
+# host-scan hand-over and the multi-pipeline run.  Afterwards, on the build machine:  bash tools/collect_profiles.sh <tag>
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
-B="python bench.py --cpu-scans 0 --no-kernel-events --steady-scans 0"
-timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
-timeout 400 python bench.py 2>/dev/null | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
-timeout 300 $B --steps 300 2>/dev/null | tail -1 > "$O/bench_300_steps.json"
-timeout 300 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --steady-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
-timeout 300 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o f --output-format csv -- $B --steps 30 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o w --output-format csv -- $B --steps 30 > /dev/null 2>&1
-timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES -d "$O/pmc_sq1" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq1.log" 2>&1
-timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d "$O/pmc_sq2" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq2.log" 2>&1
-timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS -d "$O/pmc_sq3" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq3.log" 2>&1
+export SUMA_SCAN_CACHE=/tmp/suma_scans
+B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0"
+SUMA_FULL_CONFIGS=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
+timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
+timeout 900 $B --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
+timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o f --output-format csv -- $B --steps 30 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o w --output-format csv -- $B --steps 30 > /dev/null 2>&1
+timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES -d "$O/pmc_sq1" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq1.log" 2>&1
+timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d "$O/pmc_sq2" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq2.log" 2>&1
+timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS -d "$O/pmc_sq3" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq3.log" 2>&1
 timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
 # BASELINE configs[2] / configs[3] on ONE GPU (the driver owns the 8-GPU runs), the host-scan hand-over, 4 pipelines per GPU
-timeout 300 python bench.py --mode hypotheses --steps 40 2>/dev/null | tail -1 > "$O/bench_hypotheses.json"
-timeout 400 python bench.py --mode sequences11 --steps 40 2>/dev/null | tail -1 > "$O/bench_sequences11.json"
+timeout 300 python bench.py --mode hypotheses --steps 60 2>/dev/null | tail -1 > "$O/bench_hypotheses.json"
+SUMA_SEQ_CONCURRENT=2 timeout 400 python bench.py --mode sequences11 2>/dev/null | tail -1 > "$O/bench_sequences11.json"
+timeout 300 python bench.py --mode adapter --adapter-scans 300 2>/dev/null | tail -1 > "$O/adapter_path_300_scans.json"
 timeout 300 python tools/ingest_bench.py 2>/dev/null | tail -1 > "$O/ingest.json"
 timeout 300 python tools/multi_seq.py 4 60 2>/dev/null | tail -1 > "$O/multi_seq.txt"
-cat "$O/pytest_gpu.txt"; cut -c1-300 "$O/bench.json"; ls "$O"
+cat "$O/pytest_gpu.txt"; cut -c1-400 "$O/bench.json"; cut -c1-300 "$O/bench_full_sequence_4541.json"; ls "$O"

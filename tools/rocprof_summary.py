@@ -27,7 +27,7 @@ def main():
     rows = rows_from_db(path) if path.endswith(".db") else rows_from_csv(path)
     agg = defaultdict(list)
     for name, ns in rows:
-        agg[name.split("(")[0]].append(ns)
+        agg[name.split("(")[0].replace("void ", "").split("<")[0]].append(ns)
     tot = sum(sum(v) for v in agg.values())
     print(f"# rocprofv3 --kernel-trace summary of {path}")
     print(f"{'kernel':<34}{'calls':>8}{'total_ms':>11}{'avg_us':>10}{'min_us':>10}{'max_us':>10}{'share':>8}")

@@ -24,7 +24,7 @@ def main():
         except OSError:
             continue
         for r in rows:
-            by[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            by[r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("# per-launch means of SQ counters (rocprofv3 --pmc, separate passes of `python bench.py --steps 30`), quad-cycle units")
     for k in WANT:
         if k not in by:

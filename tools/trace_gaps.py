@@ -9,7 +9,7 @@ import sys
 def main():
     rows = []
     for r in csv.DictReader(open(sys.argv[1])):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0], r.get("Queue_Id", "")))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0], r.get("Queue_Id", "")))
     rows.sort()
     # scans are delimited by k1_scatter launches
     starts = [i for i, r in enumerate(rows) if r[2] == "k1_scatter"]
