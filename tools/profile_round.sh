@@ -10,7 +10,7 @@ TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 export SUMA_SCAN_CACHE=/tmp/suma_scans
 B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0"
-SUMA_FULL_CONFIGS=1 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
+timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
 timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
 timeout 900 $B --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
 timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
