@@ -495,10 +495,21 @@ extern "C" int suma_debug_k9_phases(unsigned long long* host, int reset) {
 }
 #endif
 
-__global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
-  __shared__ float4 s_out[2][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
-  __shared__ uint16_t s_slot[2][SUMA_TILE]; /* stable rank -> slot */
-  __shared__ uint8_t s_ext[2][SUMA_TILE];   /* slot -> "in the tile that is extracted after this update" */
+/* K9_DEFER 1: one block per CU, records double buffered, a tile's offset collected one tile later (the default).
+ * K9_DEFER 0: records single buffered (68 KB), so that TWO blocks share a CU (with K9_PER = 2: 2 x 512 threads); a
+ * block waits for its offset right after publishing, and the other block's work fills the wait. */
+#ifndef K9_DEFER
+#define K9_DEFER 1
+#endif
+#define K9_BUFS (K9_DEFER ? 2 : 1)
+__global__ void __launch_bounds__(K9_THREADS)
+#if !K9_DEFER
+    __attribute__((amdgpu_waves_per_eu(2 * K9_WAVES / 4, 2 * K9_WAVES / 4)))
+#endif
+    k9_update(UpdArgs a) {
+  __shared__ float4 s_out[K9_BUFS][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
+  __shared__ uint16_t s_slot[K9_BUFS][SUMA_TILE]; /* stable rank -> slot */
+  __shared__ uint8_t s_ext[K9_BUFS][SUMA_TILE];   /* slot -> "in the tile that is extracted after this update" */
   __shared__ uint32_t s_cnt_emit[K9_PER][K9_WAVES], s_cnt_keep[K9_WAVES];
   __shared__ uint32_t s_tile, s_prefix;
   const uint32_t S = a.ds->n_surfels;
@@ -619,7 +630,32 @@ __global__ void __launch_bounds__(K9_THREADS) k9_update(UpdArgs a) {
     if (tile >= ntiles) break;
     prev_tile = tile;
     prev_total = total;
+#if K9_DEFER
     buf ^= 1u;
+#else
+    /* single buffer: this tile's offset and stream-out right away */
+    if (threadIdx.x < 64) {
+      const uint32_t pre = lookback_collect(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
+      if (threadIdx.x == 0) s_prefix = pre;
+    }
+    lds_barrier();
+    {
+      const uint32_t prefix = s_prefix;
+      for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
+        const uint64_t d = 4ull * prefix + c;
+        if (d < 4ull * a.max_surfels) {
+          const uint32_t slot = s_slot[0][c >> 2];
+          store_stream(&dst4[d], s_out[0][slot][c & 3u]);
+          if (a.ex_flags != nullptr && (c & 3u) == 0) a.ex_flags[d >> 2] = s_ext[0][slot];
+        }
+      }
+      if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
+        const uint32_t tot = prefix + prev_total;
+        a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
+      }
+    }
+    prev_tile = 0xffffffffu;
+#endif
   }
   PH_END(g_k9_phase);
   if (threadIdx.x == 0 && keep_count)
