@@ -337,6 +337,8 @@ class SurfelMapping {
                    int32_t fixed_iterations = 0) {
     chk(suma_pipeline_process_scan(s_, points, labels, probs, n, fixed_iterations), "SurfelMapping::processScan");
   }
+  /* SurfelMapping::reset(), SurfelMapping.cpp:131-169 */
+  void reset() { chk(suma_pipeline_reset(s_), "SurfelMapping::reset"); }
   /* ---- device parts of checkLoopClosure ---- */
   /* :546-574, a tracked closure verified again; on success the caller sets currentPose_old_ = out.pose_old (:581) */
   suma_loop_track trackLoopClosure(double min_valid = 0.2, double max_outlier = 0.85, double max_diff = 0.1) {
