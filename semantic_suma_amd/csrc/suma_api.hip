@@ -1228,7 +1228,14 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
   memset(s->h_res, 0, 3 * sizeof(HostResult));
   /* side stream for work off the critical path of a scan (k_sync.hip); SUMA_NO_SIDE_STREAM=1 keeps everything on
    * the ctx stream (A/B measurements) */
-  if (!getenv("SUMA_NO_SIDE_STREAM")) {
+  /* The in-memory hand-off between the two streams (k_sync.hip) needs both streams to make progress side by side: the
+   * gate kernel on one spins until the signal kernel on the other has run.  A tool that SERIALISES kernel execution
+   * breaks that (the gate runs alone, the signal never starts, the bounded spin ends in SUMA_ERR_HIP after seconds):
+   * rocprofv3 --pmc does (counter collection; it exports ROCPROF_COUNTER_COLLECTION), and so does
+   * AMD_SERIALIZE_KERNEL.  Under either the pipeline keeps everything on the ctx stream. */
+  const char* ser = getenv("AMD_SERIALIZE_KERNEL");
+  const bool serialised = getenv("ROCPROF_COUNTER_COLLECTION") != nullptr || (ser && atoi(ser) != 0);
+  if (!getenv("SUMA_NO_SIDE_STREAM") && !serialised) {
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void**)&c->zbuf_k1, c->P * 8) != hipSuccess ||
         hipMemsetAsync(c->zbuf_k1, 0xFF, c->P * 8, c->stream) != hipSuccess ||
