@@ -7,7 +7,7 @@ import numpy as np
 sys.path.insert(0, '.')
 from semantic_suma_amd import core, synth
 from semantic_suma_amd.types import params_with_size
-W, K, Wu = 2048, 60, 5
+W, K, Wu = 2048, 240, 10  # long enough that the three-scan head start of the staging is noise
 p = params_with_size(W)
 scans = [synth.generate_scan(k, n_azimuth=W)[:3] for k in range(Wu + K)]
 out = {}
