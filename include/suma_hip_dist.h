@@ -35,6 +35,12 @@ int suma_gather(suma_ctx* ctx, suma_dist_comm* comm, const double* send, uint32_
 /* the gather of SURVEY.md 8(b): each rank's 4x4 pose (column-major doubles); all_poses = world x 16 doubles */
 int suma_gather_poses(suma_ctx* ctx, suma_dist_comm* comm, const double pose[16], double* all_poses);
 
+/* element-wise sum over the ranks of `count` doubles (any count), on a stream of the library's own; blocks until the
+ * result is on the host.  suma_dist_exchange has the signature of suma_exchange_fn (include/suma_runner.h): BASELINE
+ * configs[2] from a C++ host is  suma_run_hypotheses(&params, device, &job, 0, suma_dist_exchange, comm, poses, winners, err). */
+int suma_dist_allreduce_sum(suma_dist_comm* comm, const double* send, uint32_t count, double* out);
+int suma_dist_exchange(void* comm, const double* local, double* all, uint32_t n_doubles);
+
 #ifdef __cplusplus
 }
 #endif

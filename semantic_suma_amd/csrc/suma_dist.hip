@@ -115,3 +115,40 @@ extern "C" int suma_gather(suma_ctx* ctx, suma_dist_comm* c, const double* send,
 extern "C" int suma_gather_poses(suma_ctx* ctx, suma_dist_comm* c, const double pose[16], double* all_poses) {
   return suma_gather(ctx, c, pose, 16, all_poses);
 }
+
+/* Element-wise sum over the ranks of a table of doubles: the exchange step of suma_run_hypotheses (include/suma_runner.h;
+ * every row of the n_hyp x 18 table is owned by exactly one rank and zero elsewhere, so the sum IS the gathered table).
+ * ncclAllReduce on a stream of its own -- the runner's pipeline is internal to it -- in chunks of the staging block. */
+extern "C" int suma_dist_allreduce_sum(suma_dist_comm* c, const double* send, uint32_t count, double* out) {
+  if (!c || !send || !out || count == 0) return SUMA_ERR_INVALID;
+  static thread_local hipStream_t stream = nullptr;
+  if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
+    c->err = "suma_dist_allreduce_sum: hipStreamCreate failed";
+    return SUMA_ERR_HIP;
+  }
+  for (uint32_t lo = 0; lo < count; lo += SUMA_DIST_MAX_DOUBLES) {
+    const uint32_t n = count - lo < SUMA_DIST_MAX_DOUBLES ? count - lo : SUMA_DIST_MAX_DOUBLES;
+    memcpy(c->h_buf, send + lo, n * sizeof(double));
+    if (hipMemcpyAsync(c->d_send, c->h_buf, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) {
+      c->err = "suma_dist_allreduce_sum: upload failed";
+      return SUMA_ERR_HIP;
+    }
+    ncclResult_t r = ncclAllReduce(c->d_send, c->d_recv, n, ncclDouble, ncclSum, c->comm, stream);
+    if (r != ncclSuccess) {
+      c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
+      return SUMA_ERR_HIP;
+    }
+    double* h_recv = c->h_buf + SUMA_DIST_MAX_DOUBLES;
+    if (hipMemcpyAsync(h_recv, c->d_recv, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+        hipStreamSynchronize(stream) != hipSuccess) {
+      c->err = "suma_dist_allreduce_sum: download failed";
+      return SUMA_ERR_HIP;
+    }
+    memcpy(out + lo, h_recv, n * sizeof(double));
+  }
+  return SUMA_OK;
+}
+/* the same with the signature of suma_exchange_fn: pass it to suma_run_hypotheses with user = the suma_dist_comm */
+extern "C" int suma_dist_exchange(void* user, const double* local, double* all, uint32_t n_doubles) {
+  return suma_dist_allreduce_sum((suma_dist_comm*)user, local, n_doubles, all);
+}

@@ -838,6 +838,23 @@ payload = np.linspace(0, 1, 21)
 out2 = np.zeros(21)
 assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 21, out2.ctypes.data) == 0 and np.array_equal(out2, payload)
 assert D.suma_gather(ctx.h, comm, payload.ctypes.data, 65, out2.ctypes.data) != 0  # over the 64-double limit
+# the exchange step of the native hypothesis runner (suma_run_hypotheses) over RCCL: a table of any size, summed over
+# the ranks (world 1: returned as is), directly and through the suma_exchange_fn signature
+D.suma_dist_allreduce_sum.argtypes = [vp, vp, C.c_uint32, vp]
+D.suma_dist_exchange.argtypes = [vp, vp, vp, C.c_uint32]
+table = np.random.default_rng(3).normal(size=8 * 18)
+got = np.zeros_like(table)
+assert D.suma_dist_allreduce_sum(comm, table.ctypes.data, table.size, got.ctypes.data) == 0, D.suma_dist_last_error(comm)
+assert np.array_equal(got, table)
+got[:] = 0
+assert D.suma_dist_exchange(comm, table.ctypes.data, got.ctypes.data, table.size) == 0 and np.array_equal(got, table)
+# and the runner driven with it from this process (one rank: the callback is not needed, but must be accepted)
+from semantic_suma_amd import synth
+from semantic_suma_amd.distributed import hypothesis_perturbations, run_hypotheses_hip
+p9 = params_with_size(900, max_iterations=6)
+scans = [synth.generate_scan(k, n_azimuth=900)[:3] for k in range(3)]
+poses, winners = run_hypotheses_hip(p9, scans, 4)
+assert winners[0] == -1 and all(0 <= w < 4 for w in winners[1:]) and 1.5 < poses[-1][0, 3] < 3.0
 D.suma_dist_comm_destroy(comm)
 print("gather ok")
 """
