@@ -157,6 +157,11 @@ int suma_map_download_index_map(suma_ctx* ctx, uint32_t* host);      /* P, surfe
 int suma_map_download_radius_conf(suma_ctx* ctx, suma_float4* host); /* P */
 int suma_map_download_integrated(suma_ctx* ctx, uint8_t* host);      /* P */
 int suma_map_counts(suma_ctx* ctx, uint32_t* n_updated, uint32_t* n_new, uint32_t* n_cached, int32_t origin_ij[2]);
+/* the submap cache in HBM (the reference pages tiles to host vectors, SurfelMap.h:186, SurfelMap.cpp:733-734): surfels
+ * allocated from the arena (live tiles + the blocks that re-extracted tiles left behind), its capacity
+ * (suma_params.cache_surfels), and how often it has been compacted -- when it runs full the live tiles are copied into
+ * a fresh arena; SUMA_ERR_CAPACITY only if the live tiles alone do not fit */
+int suma_map_cache_stats(suma_ctx* ctx, uint32_t* used, uint32_t* capacity, uint32_t* compactions);
 
 /* ---- SurfelMapping::processScan (SurfelMapping.h:47, SurfelMapping.cpp:175-210) without the
  *      loop-closure / pose-graph part: initialize, preprocess, updatePose

@@ -148,6 +148,7 @@ def lib():
     L.suma_map_download_radius_conf.argtypes = [vp, vp]
     L.suma_map_download_integrated.argtypes = [vp, vp]
     L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
+    L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
     L.suma_pipeline_destroy.argtypes = [vp]
@@ -618,6 +619,12 @@ class SurfelMap:
         out = np.zeros((p.data_height, p.data_width), dtype=np.uint8)
         self.ctx.check(self.ctx.L.suma_map_download_integrated(self.ctx.h, _ptr(out)))
         return out
+
+    def cache_stats(self):
+        """(surfels allocated from the submap cache arena, its capacity, compactions so far)"""
+        a, b, cc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_cache_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(cc)))
+        return a.value, b.value, cc.value
 
     def counts(self):
         """(S' survivors of K9, D new surfels of K10, surfels parked in submap caches, submap origin)"""

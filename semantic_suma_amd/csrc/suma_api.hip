@@ -342,6 +342,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     if (cache > 0xffffffffull) cache = 0xffffffffull;
     c->cache_cap = (uint32_t)cache;
     CK(hipMalloc((void**)&c->cache_arena, (size_t)c->cache_cap * sizeof(suma_surfel)));
+    c->cache_compactions = 0;
     c->cache_slots_cap = 65536;
     CK(hipMalloc((void**)&c->cache_slots, (size_t)c->cache_slots_cap * sizeof(CacheSlot)));
     CK(hipMemsetAsync(c->cache_slots, 0, (size_t)c->cache_slots_cap * sizeof(CacheSlot), c->stream));
@@ -742,6 +743,51 @@ static int cache_slot_for(suma_ctx* c, int32_t i, int32_t j, uint32_t* slot) {
   return SUMA_OK;
 }
 
+/* The cache arena is a bump allocator (K12's finaliser moves DevState.cache_used): a tile that is extracted AGAIN gets a
+ * new block and leaves its old one behind, where the reference simply overwrites the tile's std::vector
+ * (SurfelMap.cpp:733-734).  When the arena is about to run full, the live blocks are copied, in slot order, into a fresh
+ * arena and the old one is freed -- rare (every few thousand scans at the default size), so a synchronous host-driven
+ * pass is fine; the stale blocks are what is reclaimed.  Returns SUMA_OK when the arena has room for one more tile. */
+static int cache_compact_if_needed(suma_ctx* c) {
+  /* the host's view of the bump pointer lags the device by at most one update (one tile, <= SUMA_EXTRACT_CAPACITY) */
+  /* room wanted for the next tile: the reference's per-tile capacity (SurfelMap.cpp:279), or an eighth of a small arena;
+   * whether the tile really fits is K12's own check (DevState.overflow bit 1) */
+  const uint64_t need = SUMA_EXTRACT_CAPACITY < c->cache_cap / 8 ? SUMA_EXTRACT_CAPACITY : c->cache_cap / 8;
+  if ((uint64_t)c->h_ds->cache_used + 2 * need <= c->cache_cap) return SUMA_OK;
+  int r = read_state(c); /* synchronises; the exact pointer */
+  if (r) return r;
+  if ((uint64_t)c->h_ds->cache_used + need <= c->cache_cap) return SUMA_OK;
+  const uint32_t ns = (uint32_t)c->cache_index.size();
+  std::vector<CacheSlot> slots(ns);
+  if (ns) CK(hipMemcpy(slots.data(), c->cache_slots, ns * sizeof(CacheSlot), hipMemcpyDeviceToHost));
+  uint64_t live = 0;
+  for (auto& q : slots) live += q.count;
+  if (live >= c->h_ds->cache_used) return SUMA_OK; /* nothing stale to reclaim */
+  suma_surfel* fresh = nullptr;
+  CK(hipMalloc((void**)&fresh, (size_t)c->cache_cap * sizeof(suma_surfel)));
+  uint32_t off = 0;
+  for (auto& q : slots) {
+    if (q.count) {
+      hipError_t e = hipMemcpyAsync(fresh + off, c->cache_arena + q.offset, (size_t)q.count * sizeof(suma_surfel),
+                                    hipMemcpyDeviceToDevice, c->stream);
+      if (e != hipSuccess) {
+        hipFree(fresh);
+        CK(e);
+      }
+    }
+    q.offset = off;
+    off += q.count;
+  }
+  if (ns) CK(hipMemcpyAsync(c->cache_slots, slots.data(), ns * sizeof(CacheSlot), hipMemcpyHostToDevice, c->stream));
+  CK(hipMemcpyAsync(&c->ds->cache_used, &off, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  hipFree(c->cache_arena);
+  c->cache_arena = fresh;
+  c->h_ds->cache_used = off;
+  c->cache_compactions += 1;
+  return SUMA_OK;
+}
+
 /* SurfelMap::extractSurfels, SurfelMap.cpp:708-742 (tiles are popped from the back) */
 static int extract_surfels(suma_ctx* c, bool partially) {
   while (!c->extraction.empty()) {
@@ -751,6 +797,8 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     submap_center(c, idx.first, idx.second, &cx, &cy);
     uint32_t slot;
     int r = cache_slot_for(c, idx.first, idx.second, &slot);
+    if (r) return r;
+    r = cache_compact_if_needed(c);
     if (r) return r;
     /* K9 / K10 of the update that has just run flagged the surfels of this very tile at their final index
      * (peek_extraction): the extraction reads one byte per surfel instead of position + creation stamp of the whole map */
@@ -1038,6 +1086,16 @@ extern "C" int suma_map_counts(suma_ctx* c, uint32_t* n_updated, uint32_t* n_new
     origin_ij[0] = c->origin_i;
     origin_ij[1] = c->origin_j;
   }
+  return SUMA_OK;
+}
+
+extern "C" int suma_map_cache_stats(suma_ctx* c, uint32_t* used, uint32_t* capacity, uint32_t* compactions) {
+  if (!c) return SUMA_ERR_INVALID;
+  int r = read_state(c);
+  if (r) return r;
+  if (used) *used = c->h_ds->cache_used;
+  if (capacity) *capacity = c->cache_cap;
+  if (compactions) *compactions = c->cache_compactions;
   return SUMA_OK;
 }
 

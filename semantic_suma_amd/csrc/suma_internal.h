@@ -184,6 +184,7 @@ struct suma_ctx {
   suma_surfel* cache_arena;
   uint32_t cache_cap;
   CacheSlot* cache_slots; /* device table */
+  uint32_t cache_compactions; /* times the arena has been compacted (cache_compact, suma_api.hip) */
   uint32_t cache_slots_cap;
   std::map<std::pair<int32_t, int32_t>, uint32_t> cache_index; /* (i,j) -> slot */
   std::vector<std::pair<int32_t, int32_t>> extraction;        /* pending tiles, used as a stack */

@@ -150,3 +150,27 @@ def test_pipeline_reset_is_a_fresh_pipeline(hip):
     assert np.array_equal(used.getCurrentPose(), fresh.getCurrentPose())
     assert used.lastStats().as_dict() == fresh.lastStats().as_dict()
     assert used.map.getAllSurfels().tobytes() == fresh.map.getAllSurfels().tobytes()
+
+
+def test_cache_arena_is_compacted_when_it_runs_full(hip, oracle_lib):
+    """The submap cache is a bump allocator in HBM; a tile that is extracted again leaves its old block behind (the
+    reference overwrites a std::vector, SurfelMap.cpp:733-734).  Small tiles and a small arena on the closed circle:
+    tiles are extracted, re-appended and extracted again lap after lap, the arena runs full, the live tiles are moved
+    into a fresh one -- and the map stays the oracle's, bit for bit."""
+    W, H = 900, 64
+    kw = dict(submap_extent=4.0, submap_dimension=2, cache_surfels=300_000)
+    p = params_with_size(W, H, **kw)
+    hp, op = hip.SurfelMapping(p), oracle_lib.OraclePipeline(p, threads=16)
+    n = 2 * ls.lap_scans() + 20
+    for k in range(n):
+        sc = ls.scan(k, W, H)
+        hp.processScan(*sc, fixed_iterations=6)
+        op.process_scan(*sc, fixed_iterations=6)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k}: pose"
+        if k % 10 == 9 or k == n - 1:
+            su, sn, cached, origin = hp.map.counts()
+            assert cached == op.ctx.map_cached_surfels() and origin == op.ctx.map_submap_origin(), f"scan {k}: cache"
+            assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k}: surfels"
+    used, cap, compactions = hp.map.cache_stats()
+    assert cap == 300_000 and compactions >= 1, (used, cap, compactions)
+    assert used <= cap
