@@ -158,7 +158,7 @@ def test_cache_arena_is_compacted_when_it_runs_full(hip, oracle_lib):
     tiles are extracted, re-appended and extracted again lap after lap, the arena runs full, the live tiles are moved
     into a fresh one -- and the map stays the oracle's, bit for bit."""
     W, H = 900, 64
-    kw = dict(submap_extent=4.0, submap_dimension=2, cache_surfels=300_000)
+    kw = dict(submap_extent=4.0, submap_dimension=2, cache_surfels=900_000)
     p = params_with_size(W, H, **kw)
     hp, op = hip.SurfelMapping(p), oracle_lib.OraclePipeline(p, threads=16)
     n = 2 * ls.lap_scans() + 20
@@ -172,5 +172,5 @@ def test_cache_arena_is_compacted_when_it_runs_full(hip, oracle_lib):
             assert cached == op.ctx.map_cached_surfels() and origin == op.ctx.map_submap_origin(), f"scan {k}: cache"
             assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k}: surfels"
     used, cap, compactions = hp.map.cache_stats()
-    assert cap == 300_000 and compactions >= 1, (used, cap, compactions)
+    assert cap == 900_000 and compactions >= 1, (used, cap, compactions)
     assert used <= cap
