@@ -14,11 +14,7 @@ timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.tx
 timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
 timeout 900 $B --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
 timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
-timeout 400 rocprofv3 --pmc FETCH_SIZE -d "$O/pmc_fetch" -o f --output-format csv -- $B --steps 30 > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc WRITE_SIZE -d "$O/pmc_write" -o w --output-format csv -- $B --steps 30 > /dev/null 2>&1
-timeout 400 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES -d "$O/pmc_sq1" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq1.log" 2>&1
-timeout 400 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_BUSY_CYCLES -d "$O/pmc_sq2" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq2.log" 2>&1
-timeout 400 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS -d "$O/pmc_sq3" -o s --output-format csv -- $B --steps 30 > "$O/pmc_sq3.log" 2>&1
+bash tools/pmc_refresh.sh "$TAG" > "$O/pmc_refresh.log" 2>&1
 timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
 # BASELINE configs[2] / configs[3] on ONE GPU (the driver owns the 8-GPU runs), the host-scan hand-over, 4 pipelines per GPU
 timeout 300 python bench.py --mode hypotheses --steps 60 2>/dev/null | tail -1 > "$O/bench_hypotheses.json"
