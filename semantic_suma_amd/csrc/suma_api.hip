@@ -198,6 +198,7 @@ static int read_state(suma_ctx* c) {
 }
 
 static int map_reset_impl(suma_ctx* c) {
+  c->cache_bound = 0;
   CK(hipMemsetAsync(c->ds, 0, sizeof(DevState), c->stream));
   CK(launch_fill_identity_poses(c));
   c->timestamp = 0;
@@ -343,6 +344,7 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     c->cache_cap = (uint32_t)cache;
     CK(hipMalloc((void**)&c->cache_arena, (size_t)c->cache_cap * sizeof(suma_surfel)));
     c->cache_compactions = 0;
+    c->cache_bound = 0;
     c->cache_slots_cap = 65536;
     CK(hipMalloc((void**)&c->cache_slots, (size_t)c->cache_slots_cap * sizeof(CacheSlot)));
     CK(hipMemsetAsync(c->cache_slots, 0, (size_t)c->cache_slots_cap * sizeof(CacheSlot), c->stream));
@@ -753,10 +755,13 @@ static int cache_compact_if_needed(suma_ctx* c) {
   /* room wanted for the next tile: the reference's per-tile capacity (SurfelMap.cpp:279), or an eighth of a small arena;
    * whether the tile really fits is K12's own check (DevState.overflow bit 1) */
   const uint64_t need = SUMA_EXTRACT_CAPACITY < c->cache_cap / 8 ? SUMA_EXTRACT_CAPACITY : c->cache_cap / 8;
-  if ((uint64_t)c->h_ds->cache_used + 2 * need <= c->cache_cap) return SUMA_OK;
+  /* the bump pointer lives on the device; the host keeps an upper bound (exact value at the last read-back + what
+   * every extraction since can have added at most) and synchronises only when the bound gets close */
+  if (c->cache_bound + need <= c->cache_cap) return SUMA_OK;
   int r = read_state(c); /* synchronises; the exact pointer */
   if (r) return r;
-  if ((uint64_t)c->h_ds->cache_used + need <= c->cache_cap) return SUMA_OK;
+  c->cache_bound = c->h_ds->cache_used;
+  if (c->cache_bound + need <= c->cache_cap) return SUMA_OK;
   const uint32_t ns = (uint32_t)c->cache_index.size();
   std::vector<CacheSlot> slots(ns);
   if (ns) CK(hipMemcpy(slots.data(), c->cache_slots, ns * sizeof(CacheSlot), hipMemcpyDeviceToHost));
@@ -784,6 +789,7 @@ static int cache_compact_if_needed(suma_ctx* c) {
   hipFree(c->cache_arena);
   c->cache_arena = fresh;
   c->h_ds->cache_used = off;
+  c->cache_bound = off;
   c->cache_compactions += 1;
   return SUMA_OK;
 }
@@ -805,6 +811,10 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     const int use_flags = (c->flagged.valid && c->flagged.i == idx.first && c->flagged.j == idx.second) ? 1 : 0;
     c->flagged.valid = false;
     CK(launch_extract(c, slot, cx, cy, c->p.submap_extent, use_flags));
+    {
+      const uint64_t most = (uint64_t)c->known_surfels + 2 * c->P; /* a tile holds at most the whole map ... */
+      c->cache_bound += most < SUMA_EXTRACT_CAPACITY ? most : SUMA_EXTRACT_CAPACITY; /* ... or K12's capacity */
+    }
     if (partially) break;
   }
   return SUMA_OK;

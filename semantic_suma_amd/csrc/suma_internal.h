@@ -185,6 +185,8 @@ struct suma_ctx {
   uint32_t cache_cap;
   CacheSlot* cache_slots; /* device table */
   uint32_t cache_compactions; /* times the arena has been compacted (cache_compact, suma_api.hip) */
+  uint64_t cache_bound;       /* host-side upper bound of DevState.cache_used: exact value at the last read-back + the
+                                 most every extraction since can have added */
   uint32_t cache_slots_cap;
   std::map<std::pair<int32_t, int32_t>, uint32_t> cache_index; /* (i,j) -> slot */
   std::vector<std::pair<int32_t, int32_t>> extraction;        /* pending tiles, used as a stack */
