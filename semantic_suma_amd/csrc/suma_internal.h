@@ -20,7 +20,10 @@
 #define SUMA_TILE 1024u       /* items per compaction tile = threads per block (16 waves) */
 #endif
 #ifndef SUMA_COMPACT_BLOCKS
-#define SUMA_COMPACT_BLOCKS 512u /* grid of the ticketed compaction kernels: 2 blocks per CU */
+#define SUMA_COMPACT_BLOCKS 256u /* grid of the ticketed compaction kernels: ONE block per CU -- their 1024-thread blocks are
+                                    resident one per CU (registers / LDS), every block draws tickets until none is left, so
+                                    a second generation of blocks only starts to draw failing tickets at the kernel's
+                                    tail (512: K9 76 -> 74 us slower, -0.7 % scans/s) */
 #endif
 #define SUMA_STREAM_BLOCKS 2048u /* grid cap of the grid-stride surfel kernels: 8 blocks of 256 per CU */
 #define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
