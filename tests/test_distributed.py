@@ -210,3 +210,35 @@ def test_hypothesis_sharding_gloo_world2(oracle_lib):
     assert (a0[:, 17] > 0).all()  # every hypothesis was evaluated by exactly one rank
     best = min(range(4), key=lambda k: a0[k, 16] / a0[k, 17])
     assert w0 == best
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run with N ranks
+    (round-3 review: --gpus was parsed and ignored); with WORLD_SIZE set, or N = 1, it is a rank and launches nothing"""
+    import argparse
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("suma_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.relaunch_command(8, argv, port=29511)
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1:] == argv  # the rank processes get this process's own arguments
+    calls = []
+
+    def fake_run(c, env):
+        calls.append((c, env))
+        return 7
+
+    ns = argparse.Namespace(gpus=8)
+    assert bench.self_launch_if_needed(ns, argv=argv, environ={"PATH": "/x"}, run=fake_run) == 7
+    (c, env), = calls
+    assert c[c.index("--nproc-per-node") + 1] == "8" and c[-len(argv):] == argv
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "WORLD_SIZE" not in env
+    # already a rank (a launcher set WORLD_SIZE), or a single GPU: run in this process
+    assert bench.self_launch_if_needed(ns, argv=argv, environ={"WORLD_SIZE": "8"}, run=fake_run) is None
+    assert bench.self_launch_if_needed(argparse.Namespace(gpus=1), argv=argv, environ={}, run=fake_run) is None
+    assert len(calls) == 1

@@ -155,6 +155,24 @@ def test_bench_contract_with_two_ranks_on_one_device():
     assert d["config"]["drift_m"] < 0.5
 
 
+def test_bench_launches_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with NO external launcher: bench.py starts torch.distributed.run itself, two ranks
+    meet in a process group (gloo here: this box has one GPU, RCCL wants one per rank) and rank 0 reports n_gpus = 2"""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SUMA_BENCH_FORCE_DEVICE"] = "0"
+    for mode, extra in (("single", ["--preroll", "0"]), ("hypotheses", []), ("sequences11", [])):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--backend",
+               "gloo", "--cpu-scans", "0", "--no-kernel-events", "--adapter-scans", "0", "--mode", mode,
+               "--width", "900"] + extra
+        out = subprocess.run(cmd, env=dict(env, SUMA_SEQ_SCALE="400"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, mode + out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["devices"] == [0], (mode, d)
+        assert d["value"] > 10
+
+
 def test_rccl_process_group_beside_the_pipeline():
     """What every rank of `bench.py --gpus N` (N > 1) does, with N = 1: a torch.distributed process group on RCCL
     (backend "nccl") lives in the same process as libsuma_hip.so, collectives on CUDA tensors (barrier, all_reduce
