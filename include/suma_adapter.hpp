@@ -11,8 +11,10 @@
 #ifndef SUMA_ADAPTER_HPP_
 #define SUMA_ADAPTER_HPP_
 
+#include <chrono>
 #include <cmath>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <stdexcept>
 #include <string>
@@ -207,12 +209,11 @@ class LieGaussNewton {
   static const int32_t CONVERGED = 0;
   explicit LieGaussNewton(Context& ctx) : ctx_(ctx) { std::memset(&stats_, 0, sizeof(stats_)); }
   int32_t minimize(Frame2Model& F, const double* T0) {
-    history_.assign(16 * 1025, 0.0);
-    uint32_t nh = 0;
     F.bind();
-    check(ctx_.get(), suma_icp_minimize(ctx_.get(), T0, pose_, history_.data(), 1025, &nh, &stats_),
-          "LieGaussNewton::minimize");
-    history_.resize(16 * (size_t)(nh < 1025 ? nh : 1025));
+    /* the pose history stays on the device until history() is called (the reference's caller only draws it,
+     * SurfelMapping.cpp:391): the minimisation costs the host one poll of a pinned record, no copy */
+    check(ctx_.get(), suma_icp_minimize(ctx_.get(), T0, pose_, nullptr, 0, &n_hist_, &stats_), "LieGaussNewton::minimize");
+    history_valid_ = false;
     std::memcpy(F.pose_, pose_, sizeof(pose_));
     F.stats_ = stats_;
     F.iteration_ = stats_.iterations;
@@ -229,7 +230,16 @@ class LieGaussNewton {
   }
   /* information(): J^T W J of the last step, 6x6 column-major (LieGaussNewton.cpp:75,103-105) */
   const double* information() const { return information_; }
-  const std::vector<double>& history() const { return history_; } /* 16 doubles per entry */
+  /* 16 doubles per entry; fetched from the device on first use after a minimisation */
+  const std::vector<double>& history() {
+    if (!history_valid_) {
+      const uint32_t n = n_hist_ < 1025 ? n_hist_ : 1025;
+      history_.assign(16 * (size_t)n, 0.0);
+      if (n) check(ctx_.get(), suma_icp_history(ctx_.get(), history_.data(), n, nullptr), "LieGaussNewton::history");
+      history_valid_ = true;
+    }
+    return history_;
+  }
   uint32_t iterationCount() const { return stats_.iterations; }
 
  private:
@@ -237,6 +247,8 @@ class LieGaussNewton {
   double pose_[16];
   double information_[36];
   std::vector<double> history_;
+  uint32_t n_hist_{0};
+  bool history_valid_{true};
   suma_icp_stats stats_;
 };
 
@@ -327,15 +339,57 @@ class SurfelMapping {
   template <class Before, class Between>
   void processScan(const suma_float4* points, const float* labels, const float* probs, uint32_t n, Before integrate,
                    Between check_loop_closure, int32_t fixed_iterations = 0) {
+    const double t_all = now();
     integrate(*this);                                                                            /* :179 */
+    double t = now();
     chk(suma_pipeline_begin_scan(s_, points, labels, probs, n), "SurfelMapping::initialize/preprocess"); /* :181-187 */
+    statistics_["initialize-time"] = 0.0; /* the frame swaps of initialize() (:323-331) are pointer swaps inside begin_scan */
+    statistics_["preprocessing-time"] = now() - t;                                              /* :187 */
+    const bool tracked = timestamp() > 0;
+    t = now();
     chk(suma_pipeline_update_pose(s_, fixed_iterations), "SurfelMapping::updatePose");          /* :192 */
-    if (timestamp() > 0) check_loop_closure(*this);                                              /* :196 */
+    if (tracked) {
+      const double dt = now() - t;
+      statistics_["icp-time"] = dt;                                                             /* :193 (and :425) */
+      statistics_["opt-time"] = dt;                                                             /* :393 */
+      statistics_["icp-overall"] = dt;                                                          /* :475 */
+      suma_icp_stats st;
+      std::memset(&st, 0, sizeof(st));
+      suma_pipeline_minimize_stats(s_, &st);
+      statistics_["num_iterations"] = (double)st.iterations;                                    /* :394 */
+      t = now();
+      check_loop_closure(*this);                                                                /* :196 */
+      statistics_["loop-time"] = now() - t;                                                     /* :197 */
+    }
+    t = now();
     chk(suma_pipeline_update_map(s_), "SurfelMapping::updateMap");                               /* :201, :209 */
+    const double dt_map = now() - t;
+    statistics_["map-update"] = dt_map;                                                          /* :800 */
+    statistics_["mapping-time"] = dt_map;                                                        /* :202 */
+    const double complete = now() - t_all;
+    statistics_["complete-time"] = complete;                                                     /* :206 */
+    statistics_["icp_percentage"] = complete > 0.0 ? statistics_["opt-time"] / complete : 0.0;  /* :207 */
   }
   void processScan(const suma_float4* points, const float* labels, const float* probs, uint32_t n,
                    int32_t fixed_iterations = 0) {
-    chk(suma_pipeline_process_scan(s_, points, labels, probs, n, fixed_iterations), "SurfelMapping::processScan");
+    auto nop = [](SurfelMapping&) {};
+    processScan(points, labels, probs, n, nop, nop, fixed_iterations);
+  }
+  /* SurfelMapping::Stats (SurfelMapping.h; filled at SurfelMapping.cpp:183-207, 393-394, 425, 475, 800): the keys the
+   * untouched GUI plots (VisualizerWindow.cpp:705), in seconds like rv::Stopwatch::toc().  They are HOST clocks around
+   * the phase calls, as the reference's are around its GL calls -- with one difference in meaning: the reference
+   * drains the GL pipeline inside every phase (glFinish), this library only waits where the host needs a result (the
+   * minimisation), so "mapping-time" is the time to ENQUEUE the update and the post-update rendering, whose GPU work
+   * overlaps the next scan's upload.  Per-kernel GPU times: gpuTimes(). */
+  const std::map<std::string, double>& getStatistics() const { return statistics_; }
+  /* GPU time per kernel group from suma_profile_get (ms summed since the last reset; needs suma_profile_enable(ctx, 1),
+   * which costs a few percent of throughput) */
+  std::map<std::string, double> gpuTimes() {
+    std::map<std::string, double> out;
+    suma_kernel_time kt[64];
+    const int n = suma_profile_get(ctx(), kt, 64);
+    for (int i = 0; i < n && i < 64; ++i) out[kt[i].name] = kt[i].total_ms;
+    return out;
   }
   /* SurfelMapping::reset(), SurfelMapping.cpp:131-169 */
   void reset() { chk(suma_pipeline_reset(s_), "SurfelMapping::reset"); }
@@ -375,7 +429,11 @@ class SurfelMapping {
 
  private:
   void chk(int rc, const char* what) const { check(suma_pipeline_ctx(s_), rc, what); }
+  static double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+  }
   suma_pipeline* s_{nullptr};
+  std::map<std::string, double> statistics_;
 };
 
 }  // namespace suma_hip

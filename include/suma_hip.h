@@ -69,6 +69,10 @@ void suma_frame_destroy(suma_frame* f);
 int suma_frame_copy(suma_ctx* ctx, suma_frame* dst, const suma_frame* src);
 int suma_frame_download(suma_ctx* ctx, const suma_frame* f, int which, suma_float4* host);
 int suma_frame_upload(suma_ctx* ctx, suma_frame* f, int which, const suma_float4* host);
+/* a frame whose maps were written through an exported device pointer (suma_frame_device_ptr / suma_frame_export) by
+ * work the library did not enqueue: tells the render de-duplication and the fused K8 products that the contents
+ * changed (every writing call of this API does so by itself) */
+int suma_frame_touch(suma_ctx* ctx, suma_frame* f);
 uint32_t suma_frame_width(const suma_frame* f);
 uint32_t suma_frame_height(const suma_frame* f);
 /* device address of one map (HIP->GL interop / zero-copy consumers) */
@@ -117,6 +121,10 @@ int suma_icp_jacobian_products(suma_ctx* ctx, const double pose[16], uint32_t it
  *      history (optional): history_cap x 16 doubles receive LieGaussNewton::history(); *n_hist = entries pushed. */
 int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], double* history, uint32_t history_cap,
                       uint32_t* n_hist, suma_icp_stats* stats);
+/* LieGaussNewton::history() (LieGaussNewton.h:44) of the last suma_icp_minimize, fetched on demand: the device always
+ * records it, the copy is only paid by callers that look at it (the reference's caller keeps it for drawing,
+ * SurfelMapping.cpp:391).  *n_hist = entries the minimisation pushed; min(that, history_cap) x 16 doubles are copied. */
+int suma_icp_history(suma_ctx* ctx, double* history, uint32_t history_cap, uint32_t* n_hist);
 /* LieGaussNewton::information() (LieGaussNewton.h:50, LieGaussNewton.cpp:75,103-105): J^T W J of the last step of the
  * last suma_icp_minimize (or of the last suma_icp_jacobian_products), 6x6 column-major */
 int suma_icp_information(suma_ctx* ctx, double information[36]);
@@ -233,6 +241,10 @@ int suma_pipeline_apply_increment(suma_pipeline* s, const double increment[16]);
 int suma_pipeline_pose(const suma_pipeline* s, double pose[16]);
 int suma_pipeline_last_increment(const suma_pipeline* s, double inc[16]);
 int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* st);
+/* the frame-to-model minimisation of the last suma_pipeline_update_pose as gn_ left it (iterations = gn_->iterationCount(),
+ * SurfelMapping.cpp:394; converged; the objective's counters after the last step) -- known when update_pose returns,
+ * unlike the statistics pass behind it (suma_pipeline_last_stats), which is read back lazily */
+int suma_pipeline_minimize_stats(const suma_pipeline* s, suma_icp_stats* st);
 uint32_t suma_pipeline_timestamp(const suma_pipeline* s);
 /* number of scans on which the frame-to-frame fallback minimisation ran (trackLoss_, SurfelMapping.cpp:441) */
 uint32_t suma_pipeline_track_loss(const suma_pipeline* s);

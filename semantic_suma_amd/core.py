@@ -130,6 +130,9 @@ def lib():
     L.suma_icp_set_data.argtypes = [vp, vp, vp]
     L.suma_icp_jacobian_products.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(IcpStats)]
     L.suma_icp_minimize.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(IcpStats)]
+    L.suma_icp_history.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.suma_frame_touch.argtypes = [vp, vp]
+    L.suma_pipeline_minimize_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_icp_minimize_batch.argtypes = [vp, vp, u32, vp, vp]
     L.suma_map_reset.argtypes = [vp]
     L.suma_map_update.argtypes = [vp, vp, vp]
@@ -331,6 +334,10 @@ class Frame:
                                                     C.byref(rb)), "suma_frame_export")
         return p.value, w.value, h.value, rb.value
 
+    def touch(self):
+        """the maps were written through an exported device pointer: tell the library (suma_frame_touch)"""
+        self.ctx.check(self.ctx.L.suma_frame_touch(self.ctx.h, self.h), "suma_frame_touch")
+
     def copy(self, other: "Frame"):
         """Frame::copy (Frame.h:49-61)"""
         self.ctx.check(self.ctx.L.suma_frame_copy(self.ctx.h, self.h, other.h), "suma_frame_copy")
@@ -454,17 +461,15 @@ class LieGaussNewton:
     def minimize(self, objective: Frame2Model, T0, history_cap: int = 64) -> int:
         T0 = _cm(T0, np.float64)
         T = np.zeros((4, 4), dtype=np.float64)
-        hist = np.zeros((history_cap, 4, 4), dtype=np.float64)
         nh = C.c_uint32(0)
         c = self.ctx
         objective._bind()
-        c.check(c.L.suma_icp_minimize(c.h, _ptr(T0), _ptr(T), _ptr(hist) if history_cap else None, history_cap,
-                                      C.byref(nh), C.byref(self.stats)), "suma_icp_minimize")
+        # the pose history stays on the device until history() asks for it (suma_icp_history)
+        c.check(c.L.suma_icp_minimize(c.h, _ptr(T0), _ptr(T), None, 0, C.byref(nh), C.byref(self.stats)), "suma_icp_minimize")
         self._pose = T.T.copy()
         objective._pose = self._pose
         objective.stats = self.stats
-        n = min(nh.value, history_cap)
-        self._history = hist[:n].transpose(0, 2, 1).copy()
+        self._history, self._history_cap = None, history_cap
         return 0
 
     def minimize_batch(self, T0s, objective: Frame2Model = None):
@@ -483,6 +488,12 @@ class LieGaussNewton:
         return self._pose
 
     def history(self):
+        if self._history is None:
+            cap = self._history_cap
+            hist = np.zeros((max(cap, 1), 4, 4), dtype=np.float64)
+            nh = C.c_uint32(0)
+            self.ctx.check(self.ctx.L.suma_icp_history(self.ctx.h, _ptr(hist), cap, C.byref(nh)), "suma_icp_history")
+            self._history = hist[:min(nh.value, cap)].transpose(0, 2, 1).copy()
         return self._history
 
     def iterationCount(self):

@@ -379,6 +379,7 @@ struct IterArgs {
   /* closing launch: report to the host directly (pinned memory), see HostResult */
   HostResult* host_out;
   uint32_t host_seq;
+  int host_full; /* class-by-class entries: the report also carries acc / JtJ / Jtr / n_hist (HostResult) */
   const DevState* ds;
   /* eval-only pixel launch that reports by itself (last block), see the end of icp_iter_body */
   HostResult* fused_report;
@@ -509,11 +510,16 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       if (blockIdx.x == 0 && lane < 42) {
         /* JtJ / Jtf of this step, one element per lane: jacobianProducts' outputs and LieGaussNewton::information_
          * (LieGaussNewton.cpp:75); the symmetric matrix is mirrored from the packed upper triangle */
+        const bool to_host = !PIXEL && g.host_full && g.host_out != nullptr && blockIdx.y == 0;
         if (lane < 36) {
           const int i = lane % 6, j = lane / 6, lo = i < j ? i : j, hi = i < j ? j : i;
-          gout->JtJ[lane] = s_val[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+          const double v = s_val[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)];
+          gout->JtJ[lane] = v;
+          if (to_host) g.host_out->JtJ[lane] = v;
         } else {
-          gout->Jtr[lane - 36] = s_val[21 + (lane - 36)];
+          const double v = s_val[21 + (lane - 36)];
+          gout->Jtr[lane - 36] = v;
+          if (to_host) g.host_out->Jtr[lane - 36] = v;
         }
       }
       uint32_t k = gin->k, n_hist = gin->n_hist, converged = gin->converged, hist_slot = 0xffffffffu;
@@ -615,9 +621,18 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     gout->outlier = gin->outlier;
     gout->invalid = gin->invalid;
     if (done_in) {
+      const bool to_host = !PIXEL && g.host_full && g.host_out != nullptr && blockIdx.y == 0;
       for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = gin->acc[w];
-      for (int w = 0; w < 36; ++w) gout->JtJ[w] = gin->JtJ[w]; /* information() of a chain that has converged */
-      for (int w = 0; w < 6; ++w) gout->Jtr[w] = gin->Jtr[w];
+      for (int w = 0; w < 36; ++w) { /* information() of a chain that has converged */
+        const double v = gin->JtJ[w];
+        gout->JtJ[w] = v;
+        if (to_host) g.host_out->JtJ[w] = v;
+      }
+      for (int w = 0; w < 6; ++w) {
+        const double v = gin->Jtr[w];
+        gout->Jtr[w] = v;
+        if (to_host) g.host_out->Jtr[w] = v;
+      }
     }
   }
 
@@ -646,6 +661,7 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         h->k = gout->k;
         h->converged = gout->converged;
         h->iteration = gout->iteration;
+        h->n_hist = gout->n_hist;
         h->ds = *g.ds;
         __threadfence_system();
         __hip_atomic_store(&h->seq, g.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -836,12 +852,13 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         const long long n_valid = readlane_ll(s, 29), n_outlier = readlane_ll(s, 30), n_inlier = n_valid - n_outlier;
         const long long n_invalid = readlane_ll(s, 31);
         const int w = threadIdx.x;
-        if (w == 28) s -= n_inlier * MAGIC_BITS;
+        if (w < 27 || w == 28) s -= n_inlier * MAGIC_BITS; /* the same bias rule as the consume step above */
         if (w == 27) s -= n_valid * MAGIC_BITS;
         const double v = (double)s * (1.0 / SUMA_ACC_SCALE);
         HostResult* __restrict__ h = g.fused_report;
         if (w == 27) h->F = v;
         if (w == 28) h->F_inlier = v;
+        if (g.host_full) h->acc[w] = s; /* Frame2Model::jacobianProducts through the C-ABI: JtJ / Jtr are formed by the host */
         if (w == 0) {
           h->valid = (uint32_t)n_valid;
           h->outlier = (uint32_t)n_outlier;
@@ -961,6 +978,7 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.pose_block = c->pose_block;
   g.host_out = pixel ? nullptr : c->gn_host_out;
   g.host_seq = c->gn_host_seq;
+  g.host_full = c->gn_host_full;
   g.ds = c->ds;
   g.fused_report = (pixel && eval_only && n_hyp == 1) ? c->gn_fused_report : nullptr;
   g.fused_counter = &c->ds->reserved0;

@@ -81,6 +81,13 @@ static void derive(suma_ctx* c) {
     }                                                                            \
   } while (0)
 
+/* ctx-stream access bookkeeping of a frame (suma_frame.last_access) */
+static inline void accessed(suma_ctx* c, const suma_frame* f) {
+  if (f) const_cast<suma_frame*>(f)->last_access = ++c->enq_seq;
+}
+/* the host has just observed the completion of everything the ctx stream held */
+static inline void host_synced(suma_ctx* c) { c->done_seq = c->enq_seq; }
+
 static int fail(suma_ctx* c, int code, const char* msg) {
   c->err = msg;
   return code;
@@ -199,7 +206,16 @@ static int read_state(suma_ctx* c) {
 
 static int map_reset_impl(suma_ctx* c) {
   c->cache_bound = 0;
+  if (c->k7.valid) CK(launch_clear_index_zbuf(c)); /* an index-map splat nobody will consume */
   CK(hipMemsetAsync(c->ds, 0, sizeof(DevState), c->stream));
+  /* slot ids restart at 0 with the cleared index: the device table must not keep the previous sequence's
+   * (offset, count) pairs (the compaction would count them as live blocks) */
+  if (c->cache_slots) CK(hipMemsetAsync(c->cache_slots, 0, (size_t)c->cache_slots_cap * sizeof(CacheSlot), c->stream));
+  c->cache_compactions = 0;
+  c->cache_nothing_stale = false;
+  c->flagged.valid = false;
+  c->k7_spec.on = true;
+  c->k7_spec.have_last = false;
   CK(launch_fill_identity_poses(c));
   c->timestamp = 0;
   c->cur = 0;
@@ -330,12 +346,17 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMalloc((void**)&c->gn_T0s, (size_t)SUMA_MAX_HYP * 16 * sizeof(double)));
     CK(hipHostMalloc((void**)&c->h_gn, SUMA_MAX_HYP * sizeof(GnState), hipHostMallocDefault));
     CK(hipMalloc((void**)&c->pose_block, 32 * sizeof(float)));
+    CK(hipHostMalloc((void**)&c->h_rec, 2 * sizeof(HostResult), hipHostMallocDefault));
+    memset(c->h_rec, 0, 2 * sizeof(HostResult));
+    c->rec_seq = 0;
+    c->gn_host_full = 0;
     c->gn_emit_pose = 0;
     c->gn_host_out = nullptr;
     c->gn_fused_report = nullptr;
     c->gn_fuse_k8 = 0;
     c->k8_fused_frame = nullptr;
     c->gn_host_seq = 0;
+    c->cache_slots = nullptr;
     /* submap cache arena */
     /* default 16 x max_surfels (4.3 GB at the reference's 4.19 M): every tile of a KITTI-length
      * trajectory stays parked in HBM; re-extracted tiles take fresh arena space */
@@ -347,7 +368,6 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     c->cache_bound = 0;
     c->cache_slots_cap = 65536;
     CK(hipMalloc((void**)&c->cache_slots, (size_t)c->cache_slots_cap * sizeof(CacheSlot)));
-    CK(hipMemsetAsync(c->cache_slots, 0, (size_t)c->cache_slots_cap * sizeof(CacheSlot), c->stream));
     int r = frame_create_raw(c, params->model_width, params->model_height, &c->old_frame);
     if (r) return r;
     r = frame_create_raw(c, params->model_width, params->model_height, &c->new_frame);
@@ -372,11 +392,16 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
 extern "C" void suma_ctx_destroy(suma_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
+  ingest_destroy(c);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->side_stream) {
     hipStreamSynchronize(c->side_stream);
+    side_stream_released(c);
     hipStreamDestroy(c->side_stream);
+    if (c->pre_event) hipEventDestroy(c->pre_event);
+    if (c->order_event) hipEventDestroy(c->order_event);
   }
+  if (c->h_rec) hipHostFree(c->h_rec);
   for (auto& ev : c->prof_events) {
     hipEventDestroy(ev.a);
     hipEventDestroy(ev.b);
@@ -440,23 +465,35 @@ extern "C" void suma_frame_destroy(suma_frame* f) {
 extern "C" int suma_frame_copy(suma_ctx* c, suma_frame* dst, const suma_frame* src) {
   if (!c || !dst || !src || dst->width != src->width || dst->height != src->height) return SUMA_ERR_INVALID;
   size_t bytes = 3 * (size_t)src->width * src->height * sizeof(float4);
-  if (c->rendered.out == dst) c->rendered.valid = false;
+  if (c->gate_pending) CK(flush_gate(c));
+  dst->version++;
+  accessed(c, dst);
+  accessed(c, src);
   CK(hipMemcpyAsync(dst->map[0], src->map[0], bytes, hipMemcpyDeviceToDevice, c->stream));
   return SUMA_OK;
 }
 extern "C" int suma_frame_download(suma_ctx* c, const suma_frame* f, int which, suma_float4* host) {
   if (!c || !f || !host || which < 0 || which > 2) return SUMA_ERR_INVALID;
   size_t bytes = (size_t)f->width * f->height * sizeof(float4);
+  if (c->gate_pending) CK(flush_gate(c));
   CK(hipMemcpyAsync(host, f->map[which], bytes, hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
+  host_synced(c);
+  return SUMA_OK;
+}
+extern "C" int suma_frame_touch(suma_ctx* c, suma_frame* f) {
+  if (!c || !f) return SUMA_ERR_INVALID;
+  f->version++;
   return SUMA_OK;
 }
 extern "C" int suma_frame_upload(suma_ctx* c, suma_frame* f, int which, const suma_float4* host) {
   if (!c || !f || !host || which < 0 || which > 2) return SUMA_ERR_INVALID;
   size_t bytes = (size_t)f->width * f->height * sizeof(float4);
-  c->rendered.valid = false;
+  if (c->gate_pending) CK(flush_gate(c));
+  f->version++;
   CK(hipMemcpyAsync(f->map[which], host, bytes, hipMemcpyHostToDevice, c->stream));
   CK(hipStreamSynchronize(c->stream));
+  host_synced(c);
   return SUMA_OK;
 }
 extern "C" uint32_t suma_frame_width(const suma_frame* f) { return f ? f->width : 0; }
@@ -469,13 +506,14 @@ extern "C" int suma_frame_swap(suma_ctx* c, suma_frame* a, suma_frame* b) {
   if (!c || !a || !b) return SUMA_ERR_INVALID;
   if (a->width != b->width || a->height != b->height) return fail(c, SUMA_ERR_INVALID, "suma_frame_swap: sizes differ");
   for (int m = 0; m < 3; ++m) std::swap(a->map[m], b->map[m]);
-  c->rendered.valid = false;
-  if (c->k8_fused_frame == a || c->k8_fused_frame == b) c->k8_fused_frame = nullptr;
+  a->version++;
+  b->version++;
   return SUMA_OK;
 }
 extern "C" int suma_frame_export(suma_ctx* c, const suma_frame* f, int which, void** d_ptr, uint32_t* width,
                                  uint32_t* height, uint32_t* row_bytes) {
   if (!c || !f || !d_ptr || which < 0 || which > 2) return SUMA_ERR_INVALID;
+  if (c->gate_pending) CK(flush_gate(c)); /* a consumer ordered behind the ctx stream sees the finished frame */
   *d_ptr = (void*)f->map[which];
   if (width) *width = f->width;
   if (height) *height = f->height;
@@ -515,7 +553,10 @@ extern "C" int suma_preprocess_device(suma_ctx* c, const suma_float4* d_points, 
   if (!c || !out || (n > 0 && !d_points)) return SUMA_ERR_INVALID;
   if (out->width != c->p.data_width || out->height != c->p.data_height)
     return fail(c, SUMA_ERR_INVALID, "suma_preprocess: frame size differs from data_width x data_height");
-  if (c->k8_fused_frame == out) c->k8_fused_frame = nullptr; /* the frame's maps are about to change */
+  /* a second preprocessing while one is still pending on the side stream: keep them in order */
+  if (c->gate_pending && c->ls == c->stream) CK(flush_gate(c));
+  out->version++; /* the frame's maps are about to change (render de-duplication, fused K8 products) */
+  if (c->ls == c->stream) accessed(c, out);
   CK(launch_preprocess(c, (const float4*)d_points, d_labels, d_probs, n, timestamp, out));
   return SUMA_OK;
 }
@@ -540,13 +581,53 @@ static int stage_scan(suma_ctx* c, const suma_float4* points, const float* label
   return SUMA_OK;
 }
 
+/* Preprocessing::process from the host vectors the reference's caller holds (Preprocessing.cpp:120-189 starts with
+ * the glBufferData of Frame::points.assign): the scan is staged through pinned memory and the copy stream
+ * (suma_ingest.hip) and K1-K3 run on the side stream behind the upload -- the call returns once the work is enqueued,
+ * the render() that follows it in SurfelMapping::preprocess (SurfelMapping.cpp:344-351) does not read the frame and
+ * overlaps it, and the first call that does read the frame waits on the device (flush_gate).  SUMA_PREPROCESS_SYNC=1
+ * restores the pageable copy on the ctx stream. */
 extern "C" int suma_preprocess(suma_ctx* c, const suma_float4* points, const float* labels, const float* probs,
                                uint32_t n, uint32_t timestamp, suma_frame* out) {
   if (!c || !out || (n > 0 && !points)) return SUMA_ERR_INVALID;
-  int r = stage_scan(c, points, labels, probs, n);
+  static const bool plain = getenv("SUMA_PREPROCESS_SYNC") != nullptr;
+  if (plain) {
+    int r = stage_scan(c, points, labels, probs, n);
+    if (r) return r;
+    return suma_preprocess_device(c, (const suma_float4*)c->scan_points, labels ? c->scan_labels : nullptr,
+                                  probs ? c->scan_probs : nullptr, n, timestamp, out);
+  }
+  if (c->gate_pending) CK(flush_gate(c)); /* one hand-off at a time */
+  int r = ensure_side_stream(c);
   if (r) return r;
-  return suma_preprocess_device(c, (const suma_float4*)c->scan_points, labels ? c->scan_labels : nullptr,
-                                probs ? c->scan_probs : nullptr, n, timestamp, out);
+  const suma_float4* dp;
+  const float *dl, *dq;
+  hipEvent_t up;
+  void* slot;
+  r = ingest_stage_blocking(c, points, labels, probs, n, &dp, &dl, &dq, &up, &slot);
+  if (r) return r;
+  if (c->side_stream) {
+    /* the side stream must not overwrite the frame while earlier ctx-stream work still touches it: only if the
+     * frame's last access on the ctx stream is younger than the last completion the host has observed (in
+     * SurfelMapping::processScan it never is: the frame is the one of two scans ago, and the host has waited for a
+     * minimisation since) is the side stream ordered behind the ctx stream -- otherwise K1-K3 overlap the
+     * previous scan's surfel passes, as in the scan pipeline. */
+    if (out->last_access > c->done_seq) {
+      CK(hipEventRecord(c->order_event, c->stream));
+      CK(hipStreamWaitEvent(c->side_stream, c->order_event, 0));
+    }
+    CK(hipStreamWaitEvent(c->side_stream, up, 0));
+    c->ls = c->side_stream;
+    r = suma_preprocess_device(c, dp, dl, dq, n, timestamp, out);
+    c->ls = c->stream;
+    ingest_consumed(c, slot, c->side_stream);
+    if (r) return r;
+    return side_handoff(c, out);
+  }
+  CK(hipStreamWaitEvent(c->stream, up, 0));
+  r = suma_preprocess_device(c, dp, dl, dq, n, timestamp, out);
+  ingest_consumed(c, slot, c->stream);
+  return r;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -602,6 +683,7 @@ static void fill_stats_host(const HostResult& g, suma_icp_stats* st) {
 static int wait_host_result(suma_ctx* c, const HostResult* h, uint32_t seq) {
   for (uint32_t spins = 1;; ++spins) {
     if (__atomic_load_n(&h->seq, __ATOMIC_ACQUIRE) == seq) return SUMA_OK;
+    __builtin_ia32_pause();
     if ((spins & 0xfffu) == 0) {
       hipError_t q = hipStreamQuery(c->stream);
       if (q == hipSuccess) { /* everything has run: the record must be there */
@@ -613,26 +695,65 @@ static int wait_host_result(suma_ctx* c, const HostResult* h, uint32_t seq) {
   }
 }
 
+/* host side of a HostResult.acc report: JtJ (6x6 column-major, mirrored from the packed upper triangle), Jtr and the
+ * GnState copy suma_icp_information reads -- the same value the device forms, (double)word * 2^-28 */
+static void unpack_acc(suma_ctx* c, const HostResult& h, double* JtJ, double* Jtr, int64_t* acc) {
+  GnState& g = c->h_gn[0];
+  for (int w = 0; w < (int)SUMA_ACC_WORDS; ++w) g.acc[w] = h.acc[w];
+  for (int k = 0; k < 36; ++k) {
+    const int i = k % 6, j = k / 6, lo = i < j ? i : j, hi = i < j ? j : i;
+    g.JtJ[k] = (double)h.acc[lo * 6 - (lo * (lo - 1)) / 2 + (hi - lo)] * (1.0 / SUMA_ACC_SCALE);
+  }
+  for (int k = 0; k < 6; ++k) g.Jtr[k] = (double)h.acc[21 + k] * (1.0 / SUMA_ACC_SCALE);
+  if (JtJ) memcpy(JtJ, g.JtJ, sizeof(g.JtJ));
+  if (Jtr) memcpy(Jtr, g.Jtr, sizeof(g.Jtr));
+  if (acc) memcpy(acc, g.acc, sizeof(g.acc));
+}
+
 extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], uint32_t iteration, double JtJ[36],
                                           double Jtr[6], int64_t* acc, suma_icp_stats* stats) {
   if (!c || !pose) return SUMA_ERR_INVALID;
   if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
+  if (c->gate_pending) CK(flush_gate(c));
+  accessed(c, c->icp_current);
+  accessed(c, c->icp_model);
   CK(launch_gn_init(c, pose, 1, 0, iteration));
+  /* ONE launch: the pixel pass closes itself (its last block totals the accumulator records) and reports the sums
+   * straight into a pinned host record the host polls -- no consume-only launch, no copy command, no stream
+   * synchronisation (round 3: two launches + hipMemcpyAsync + hipStreamSynchronize).  If the frame is data-sized and
+   * its K8 products (init_radiusConf.vert: pose independent) do not exist yet for this timestamp, the pass forms them
+   * on the texels it streams anyway, as the scan pipeline's statistics pass does: the reference evaluates the
+   * objective on currentFrame_ right before updateMap (SurfelMapping.cpp:411-413 -> :799). */
+  const suma_frame* cur = c->icp_current;
+  const bool k8_wanted = cur->width == c->p.data_width && cur->height == c->p.data_height &&
+                         !(c->k8_fused_frame == cur && c->k8_fused_version == cur->version &&
+                           c->k8_fused_stamp == c->timestamp && c->k8_fused_params == c->params_version);
+  HostResult* rec = &c->h_rec[1];
+  c->rec_seq += 1;
   {
-    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->icp_current->width * c->icp_current->height);
-    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1));
+    ProfScope ps(c, k8_wanted ? "k6k8_stats_radius" : "k6_icp_step", (96.0 + (k8_wanted ? 81.0 : 0.0)) * (double)cur->width * cur->height);
+    c->gn_fused_report = rec;
+    c->gn_host_seq = c->rec_seq;
+    c->gn_host_full = 1;
+    c->gn_fuse_k8 = k8_wanted ? 1 : 0;
+    hipError_t e = launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 1);
+    c->gn_fuse_k8 = 0;
+    c->gn_host_full = 0;
+    c->gn_fused_report = nullptr;
+    CK(e);
   }
-  {
-    ProfScope ps(c, "k6_icp_finish", 0.0);
-    CK(launch_icp_iteration(c, 1, 1, 0.0, 0.0, 1, 0, 0));
+  if (k8_wanted) {
+    c->k8_fused_frame = cur;
+    c->k8_fused_version = cur->version;
+    c->k8_fused_stamp = c->timestamp;
+    c->k8_fused_params = c->params_version;
   }
-  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-  CK(hipStreamSynchronize(c->stream));
-  const GnState& g = c->h_gn[0];
-  if (JtJ) memcpy(JtJ, g.JtJ, sizeof(g.JtJ));
-  if (Jtr) memcpy(Jtr, g.Jtr, sizeof(g.Jtr));
-  if (acc) memcpy(acc, g.acc, sizeof(g.acc));
-  fill_stats(g, stats);
+  const uint64_t mark = c->enq_seq;
+  int r = wait_host_result(c, rec, c->rec_seq);
+  if (r) return r;
+  c->done_seq = mark;
+  unpack_acc(c, *rec, JtJ, Jtr, acc);
+  fill_stats_host(*rec, stats);
   if (stats) stats->iterations = 0;
   return SUMA_OK;
 }
@@ -647,6 +768,8 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
   const uint32_t max_iter = c->p.max_iterations;
   const uint32_t iter_arg = max_iter > 0 ? max_iter : 0xffffffffu;
   if (c->gate_pending) CK(flush_gate(c)); /* the chain reads the frame the side stream preprocessed (k_sync.hip) */
+  accessed(c, c->icp_current);
+  accessed(c, c->icp_model);
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
@@ -667,6 +790,7 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
       total += SUMA_GN_CHUNK;
       CK(hipMemcpyAsync(c->h_gn, gn_result(c), (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
       CK(hipStreamSynchronize(c->stream));
+      host_synced(c);
       bool all_done = true;
       for (uint32_t h = 0; h < n_hyp; ++h) all_done = all_done && c->h_gn[h].done;
       if (all_done) break;
@@ -681,24 +805,46 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
   return SUMA_OK;
 }
 
+/* The closing launch of the chain reports into a pinned host record (pose, statistics, information matrix, history
+ * length) that the host polls: no copy command and no stream synchronisation behind the minimisation (round 3:
+ * hipMemcpyAsync + hipStreamSynchronize, and a second pair for the history).  The pose history is always recorded on
+ * the device; it crosses to the host only when asked for -- here, or later through suma_icp_history. */
 extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[16], double* history,
                                  uint32_t history_cap, uint32_t* n_hist, suma_icp_stats* stats) {
   if (!c || !T0 || !T_out) return SUMA_ERR_INVALID;
   if (!c->icp_current || !c->icp_model) return fail(c, SUMA_ERR_INVALID, "suma_icp_set_data has not been called");
-  const int with_history = (history != nullptr && history_cap > 0) ? 1 : 0;
-  int r = enqueue_minimize(c, T0, 1, with_history);
+  HostResult* rec = &c->h_rec[0];
+  c->rec_seq += 1;
+  c->gn_host_out = rec;
+  c->gn_host_seq = c->rec_seq;
+  c->gn_host_full = 1;
+  int r = enqueue_minimize(c, T0, 1, 1);
+  c->gn_host_out = nullptr;
+  c->gn_host_full = 0;
   if (r) return r;
-  CK(hipMemcpyAsync(c->h_gn, gn_result(c), sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
-  CK(hipStreamSynchronize(c->stream));
-  const GnState& g = c->h_gn[0];
-  memcpy(T_out, g.Tk, sizeof(g.Tk));
-  fill_stats(g, stats);
-  if (n_hist) *n_hist = g.n_hist;
-  if (with_history) {
-    uint32_t n = g.n_hist < history_cap ? g.n_hist : history_cap;
-    if (n > c->gn_history_cap) n = c->gn_history_cap;
+  const uint64_t mark = c->enq_seq;
+  r = wait_host_result(c, rec, c->rec_seq);
+  if (r) return r;
+  c->done_seq = mark;
+  memcpy(T_out, rec->Tk, sizeof(rec->Tk));
+  fill_stats_host(*rec, stats);
+  memcpy(c->h_gn[0].JtJ, rec->JtJ, sizeof(rec->JtJ)); /* suma_icp_information */
+  memcpy(c->h_gn[0].Jtr, rec->Jtr, sizeof(rec->Jtr));
+  c->last_n_hist = rec->n_hist;
+  if (n_hist) *n_hist = rec->n_hist;
+  if (history != nullptr && history_cap > 0) return suma_icp_history(c, history, history_cap, nullptr);
+  return SUMA_OK;
+}
+
+extern "C" int suma_icp_history(suma_ctx* c, double* history, uint32_t history_cap, uint32_t* n_hist) {
+  if (!c || (!history && history_cap)) return SUMA_ERR_INVALID;
+  if (n_hist) *n_hist = c->last_n_hist;
+  uint32_t n = c->last_n_hist < history_cap ? c->last_n_hist : history_cap;
+  if (n > c->gn_history_cap) n = c->gn_history_cap;
+  if (n) {
     CK(hipMemcpyAsync(history, c->gn_history, (size_t)n * 16 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     CK(hipStreamSynchronize(c->stream));
+    host_synced(c);
   }
   return SUMA_OK;
 }
@@ -711,6 +857,7 @@ extern "C" int suma_icp_minimize_batch(suma_ctx* c, const double* T0s, uint32_t 
   if (r) return r;
   CK(hipMemcpyAsync(c->h_gn, gn_result(c), (size_t)n_hyp * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
   CK(hipStreamSynchronize(c->stream));
+  host_synced(c);
   for (uint32_t h = 0; h < n_hyp; ++h) {
     memcpy(T_out + 16 * (size_t)h, c->h_gn[h].Tk, 16 * sizeof(double));
     if (stats) fill_stats(c->h_gn[h], &stats[h]);
@@ -750,7 +897,7 @@ static int cache_slot_for(suma_ctx* c, int32_t i, int32_t j, uint32_t* slot) {
  * (SurfelMap.cpp:733-734).  When the arena is about to run full, the live blocks are copied, in slot order, into a fresh
  * arena and the old one is freed -- rare (every few thousand scans at the default size), so a synchronous host-driven
  * pass is fine; the stale blocks are what is reclaimed.  Returns SUMA_OK when the arena has room for one more tile. */
-static int cache_compact_if_needed(suma_ctx* c) {
+static int cache_compact_if_needed(suma_ctx* c, uint32_t pending_slot) {
   /* the host's view of the bump pointer lags the device by at most one update (one tile, <= SUMA_EXTRACT_CAPACITY) */
   /* room wanted for the next tile: the reference's per-tile capacity (SurfelMap.cpp:279), or an eighth of a small arena;
    * whether the tile really fits is K12's own check (DevState.overflow bit 1) */
@@ -758,39 +905,50 @@ static int cache_compact_if_needed(suma_ctx* c) {
   /* the bump pointer lives on the device; the host keeps an upper bound (exact value at the last read-back + what
    * every extraction since can have added at most) and synchronises only when the bound gets close */
   if (c->cache_bound + need <= c->cache_cap) return SUMA_OK;
+  /* the last attempt found every allocated block live: K12's own capacity check (DevState.overflow bit 1) decides;
+   * synchronising and reading the slot table again before every extraction would buy nothing */
+  if (c->cache_nothing_stale) return SUMA_OK;
   int r = read_state(c); /* synchronises; the exact pointer */
   if (r) return r;
+  host_synced(c);
   c->cache_bound = c->h_ds->cache_used;
   if (c->cache_bound + need <= c->cache_cap) return SUMA_OK;
   const uint32_t ns = (uint32_t)c->cache_index.size();
   std::vector<CacheSlot> slots(ns);
   if (ns) CK(hipMemcpy(slots.data(), c->cache_slots, ns * sizeof(CacheSlot), hipMemcpyDeviceToHost));
+  /* the slot of the extraction that is about to be enqueued has been assigned but not written by K12 yet: whatever
+   * the table holds for it (a tile that is being re-extracted: its old block) is stale by definition */
+  if (pending_slot < ns) slots[pending_slot].count = 0;
   uint64_t live = 0;
   for (auto& q : slots) live += q.count;
-  if (live >= c->h_ds->cache_used) return SUMA_OK; /* nothing stale to reclaim */
+  if (live >= c->h_ds->cache_used) { /* nothing stale to reclaim */
+    c->cache_nothing_stale = true;
+    return SUMA_OK;
+  }
   suma_surfel* fresh = nullptr;
   CK(hipMalloc((void**)&fresh, (size_t)c->cache_cap * sizeof(suma_surfel)));
   uint32_t off = 0;
+  hipError_t e = hipSuccess;
   for (auto& q : slots) {
-    if (q.count) {
-      hipError_t e = hipMemcpyAsync(fresh + off, c->cache_arena + q.offset, (size_t)q.count * sizeof(suma_surfel),
-                                    hipMemcpyDeviceToDevice, c->stream);
-      if (e != hipSuccess) {
-        hipFree(fresh);
-        CK(e);
-      }
-    }
+    if (q.count && e == hipSuccess)
+      e = hipMemcpyAsync(fresh + off, c->cache_arena + q.offset, (size_t)q.count * sizeof(suma_surfel),
+                         hipMemcpyDeviceToDevice, c->stream);
     q.offset = off;
     off += q.count;
   }
-  if (ns) CK(hipMemcpyAsync(c->cache_slots, slots.data(), ns * sizeof(CacheSlot), hipMemcpyHostToDevice, c->stream));
-  CK(hipMemcpyAsync(&c->ds->cache_used, &off, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-  CK(hipStreamSynchronize(c->stream));
+  if (ns && e == hipSuccess) e = hipMemcpyAsync(c->cache_slots, slots.data(), ns * sizeof(CacheSlot), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&c->ds->cache_used, &off, sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) {
+    hipFree(fresh); /* the old arena and its table stay in place */
+    CK(e);
+  }
   hipFree(c->cache_arena);
   c->cache_arena = fresh;
   c->h_ds->cache_used = off;
   c->cache_bound = off;
   c->cache_compactions += 1;
+  c->cache_nothing_stale = false;
   return SUMA_OK;
 }
 
@@ -804,7 +962,7 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     uint32_t slot;
     int r = cache_slot_for(c, idx.first, idx.second, &slot);
     if (r) return r;
-    r = cache_compact_if_needed(c);
+    r = cache_compact_if_needed(c, slot);
     if (r) return r;
     /* K9 / K10 of the update that has just run flagged the surfels of this very tile at their final index
      * (peek_extraction): the extraction reads one byte per surfel instead of position + creation stamp of the whole map */
@@ -907,9 +1065,21 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
   if (c->k7.valid) { /* zbuf_data holds an index-map splat made by the post-ICP render pass */
     k7_done = (c->k7.map_version == c->map_version && c->k7.params_version == c->params_version &&
                memcmp(c->k7.pose, pose, 16 * sizeof(float)) == 0 && frame->width == c->p.data_width);
-    if (!k7_done) CK(launch_clear_index_zbuf(c)); /* different pose after all (fallback ICP): redo K7 */
+    if (!k7_done) {
+      CK(launch_clear_index_zbuf(c)); /* different pose after all (fallback ICP): redo K7 */
+      c->k7_spec.on = false;          /* a speculated splat that was paid for and dropped */
+    }
     c->k7.valid = false;
   }
+  /* speculation of suma_map_render_active: on again as soon as an update arrives that matches the last active render */
+  if (k7_done || (c->k7_spec.have_last && c->k7_spec.map_version == c->map_version &&
+                  c->k7_spec.params_version == c->params_version &&
+                  memcmp(c->k7_spec.last_pose, pose, 16 * sizeof(float)) == 0))
+    c->k7_spec.on = true;
+  c->k7_spec.have_last = false;
+  accessed(c, frame);
+  /* the K8 products of the fused statistics pass belong to the frame CONTENTS they were made from */
+  if (c->k8_fused_frame == frame && c->k8_fused_version != frame->version) c->k8_fused_frame = nullptr;
   float ex[3];
   int32_t ti = 0, tj = 0;
   const bool flag_tile = peek_extraction(c, pose, &ti, &tj);
@@ -935,11 +1105,24 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
 static int map_render_dedup(suma_ctx* c, const float* pose_old, const float* pose_new, float conf_threshold,
                             suma_frame* out) {
   auto& r = c->rendered;
+  /* the three targets still hold that rendering: nothing has written them since (suma_frame.version is bumped by every
+   * writing call, also for caller-owned frames -- round 3 gave up on those) */
   if (r.valid && r.out == out && r.map_version == c->map_version && r.params_version == c->params_version &&
+      r.out_version == out->version && r.old_version == c->old_frame->version && r.new_version == c->new_frame->version &&
       memcmp(&r.conf_threshold, &conf_threshold, sizeof(float)) == 0 &&
       memcmp(r.pose_old, pose_old, 16 * sizeof(float)) == 0 && memcmp(r.pose_new, pose_new, 16 * sizeof(float)) == 0)
     return SUMA_OK;
+  if (c->gate_pending && c->gate_frame == out) CK(flush_gate(c));
   CK(launch_map_render(c, pose_old, pose_new, conf_threshold, out));
+  out->version++;
+  if (c->old_frame != out) c->old_frame->version++;
+  if (c->new_frame != out) c->new_frame->version++;
+  accessed(c, out);
+  accessed(c, c->old_frame);
+  accessed(c, c->new_frame);
+  r.out_version = out->version;
+  r.old_version = c->old_frame->version;
+  r.new_version = c->new_frame->version;
   r.valid = true;
   r.out = out;
   r.map_version = c->map_version;
@@ -955,25 +1138,54 @@ extern "C" int suma_map_render(suma_ctx* c, const float pose_old[16], const floa
   if (!c || !pose_old || !pose_new || !out) return SUMA_ERR_INVALID;
   if (out->width != c->p.model_width || out->height != c->p.model_height)
     return fail(c, SUMA_ERR_INVALID, "suma_map_render: frame size differs from model_width x model_height");
-  c->rendered.valid = false; /* a caller-owned frame may have been written by the caller in between */
   return map_render_dedup(c, pose_old, pose_new, conf_threshold, out);
 }
 extern "C" int suma_map_render_active(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
-  c->rendered.valid = false;
-  CK(launch_map_render_single(c, pose, conf_threshold, 1, 0, nullptr));
+  if (c->gate_pending && c->gate_frame == c->new_frame) CK(flush_gate(c));
+  /* The reference's updatePose renders the active map at pose_new * increment (SurfelMapping.cpp:406) and updateMap
+   * then calls update() with that very pose (:799), whose first pass is the index map of the same surfels from the
+   * same pose (K7): the splat rides on this pass, as in the scan pipeline, and suma_map_update takes it if map,
+   * parameters and pose still match (bit for bit) -- otherwise it is cleared and K7 runs as a pass of its own.  A splat
+   * that was not consumed switches the speculation off until an update arrives that would have matched. */
+  int fuse_k7 = 0;
+  if (c->k7.valid) { /* the previous splat was never consumed */
+    CK(launch_clear_index_zbuf(c));
+    c->k7.valid = false;
+    c->k7_spec.on = false;
+  } else if (c->k7_spec.on && c->p.data_width == c->p.model_width && !getenv("SUMA_NO_K7_SPECULATION")) {
+    fuse_k7 = 1;
+  }
+  CK(launch_map_render_single(c, pose, conf_threshold, 1, fuse_k7, nullptr));
+  c->new_frame->version++;
+  accessed(c, c->new_frame);
+  if (fuse_k7) {
+    c->k7.valid = true;
+    c->k7.map_version = c->map_version;
+    c->k7.params_version = c->params_version;
+    memcpy(c->k7.pose, pose, 16 * sizeof(float));
+  }
+  c->k7_spec.have_last = true;
+  c->k7_spec.map_version = c->map_version;
+  c->k7_spec.params_version = c->params_version;
+  memcpy(c->k7_spec.last_pose, pose, 16 * sizeof(float));
   return SUMA_OK;
 }
 extern "C" int suma_map_render_inactive(suma_ctx* c, const float pose[16], float conf_threshold) {
   if (!c || !pose) return SUMA_ERR_INVALID;
-  c->rendered.valid = false;
+  if (c->gate_pending && c->gate_frame == c->old_frame) CK(flush_gate(c));
   CK(launch_map_render_single(c, pose, conf_threshold, 0, 0, nullptr));
+  c->old_frame->version++;
+  accessed(c, c->old_frame);
   return SUMA_OK;
 }
 extern "C" int suma_map_render_composed(suma_ctx* c, const float pose_old[16], const float pose_new[16],
                                         float conf_threshold) {
   if (!c || !pose_old || !pose_new) return SUMA_ERR_INVALID;
+  if (c->gate_pending && c->gate_frame == c->composed_frame) CK(flush_gate(c));
   CK(launch_map_render_composed(c, pose_old, pose_new, conf_threshold)); /* touches COMPOSED only */
+  c->composed_frame->version++;
+  accessed(c, c->composed_frame);
   return SUMA_OK;
 }
 extern "C" suma_frame* suma_map_frame(suma_ctx* c, int which) {
@@ -1294,24 +1506,12 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
     return SUMA_ERR_HIP;
   }
   memset(s->h_res, 0, 3 * sizeof(HostResult));
-  /* side stream for work off the critical path of a scan (k_sync.hip); SUMA_NO_SIDE_STREAM=1 keeps everything on
-   * the ctx stream (A/B measurements) */
-  /* The in-memory hand-off between the two streams (k_sync.hip) needs both streams to make progress side by side: the
-   * gate kernel on one spins until the signal kernel on the other has run.  A tool that SERIALISES kernel execution
-   * breaks that (the gate runs alone, the signal never starts, the bounded spin ends in SUMA_ERR_HIP after seconds):
-   * rocprofv3 --pmc does (counter collection; it exports ROCPROF_COUNTER_COLLECTION), and so does
-   * AMD_SERIALIZE_KERNEL.  Under either the pipeline keeps everything on the ctx stream. */
-  const char* ser = getenv("AMD_SERIALIZE_KERNEL");
-  const bool serialised = getenv("ROCPROF_COUNTER_COLLECTION") != nullptr || (ser && atoi(ser) != 0);
-  if (!getenv("SUMA_NO_SIDE_STREAM") && !serialised) {
-    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipMalloc((void**)&c->zbuf_k1, c->P * 8) != hipSuccess ||
-        hipMemsetAsync(c->zbuf_k1, 0xFF, c->P * 8, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
-      g_create_error = "side stream setup failed";
-      suma_pipeline_destroy(s);
-      return SUMA_ERR_HIP;
-    }
+  /* side stream for work off the critical path of a scan (k_sync.hip); SUMA_NO_SIDE_STREAM=1 or a tool that
+   * serialises kernel execution keeps everything on the ctx stream (ensure_side_stream) */
+  if (ensure_side_stream(c) != SUMA_OK) {
+    g_create_error = "side stream setup failed: " + c->err;
+    suma_pipeline_destroy(s);
+    return SUMA_ERR_HIP;
   }
   s->res_seq = 0;
   s->stats_pending = false;
@@ -1330,7 +1530,7 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
 }
 extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
   if (!s) return;
-  ingest_destroy(s);
+  ingest_destroy(s->c); /* its threads use the frames and streams freed below */
   if (s->c && s->c->stream) hipStreamSynchronize(s->c->stream);
   suma_frame_destroy(s->last_frame);
   suma_frame_destroy(s->current_frame);
@@ -1356,6 +1556,11 @@ extern "C" int suma_pipeline_last_stats(const suma_pipeline* s, suma_icp_stats* 
   int r = resolve_stats(const_cast<suma_pipeline*>(s), true);
   *st = s->stats;
   return r;
+}
+extern "C" int suma_pipeline_minimize_stats(const suma_pipeline* s, suma_icp_stats* st) {
+  if (!s || !st) return SUMA_ERR_INVALID;
+  *st = s->stats_mst;
+  return SUMA_OK;
 }
 extern "C" uint32_t suma_pipeline_timestamp(const suma_pipeline* s) { return s ? s->timestamp : 0; }
 extern "C" uint32_t suma_pipeline_track_loss(const suma_pipeline* s) { return s ? s->track_loss : 0; }
@@ -1463,6 +1668,8 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
    *     lastModelFrame copy fused in (:406-407) --- */
   c->rendered.valid = false;
   CK(launch_map_render_single(c, nullptr, conf_threshold(s), 1, 1, s->last_model));
+  c->new_frame->version++;
+  s->last_model->version++;
   /* --- statistics pass (:411-423) --- */
   double I[16];
   eye_d(I);
@@ -1483,6 +1690,7 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
     c->gn_fused_report = nullptr;
     CK(e);
     c->k8_fused_frame = s->current_frame;
+    c->k8_fused_version = s->current_frame->version;
     c->k8_fused_stamp = c->timestamp;
     c->k8_fused_params = c->params_version;
   }
@@ -1560,9 +1768,8 @@ int pipeline_begin_scan_impl(suma_pipeline* s, const suma_float4* d_points, cons
     r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
     c->ls = c->stream;
     if (r) return r;
-    c->pre_seq += 1;
-    HIP_TRY(c, launch_signal(c, c->side_stream, 0, c->pre_seq));
-    c->gate_pending = c->pre_seq; /* the first reader of the frame on the ctx stream issues the gate (flush_gate) */
+    r = side_handoff(c, s->current_frame); /* the first reader of the frame on the ctx stream issues the wait (flush_gate) */
+    if (r) return r;
   } else {
     if (upload_done) HIP_TRY(c, hipStreamWaitEvent(c->stream, upload_done, 0));
     r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp, s->current_frame);
@@ -1631,8 +1838,9 @@ extern "C" int suma_pipeline_reset(suma_pipeline* s) {
   int r = suma_synchronize(c);
   if (r) return r;
   if (c->gate_pending) c->gate_pending = 0; /* both streams have drained */
-  if (c->k7.valid) CK(launch_clear_index_zbuf(c)); /* an index-map splat nobody will consume */
-  r = map_reset_impl(c);
+  host_synced(c);
+  ingest_drain(c); /* scans staged ahead by a sequence that ended early are not this pipeline's next scans */
+  r = map_reset_impl(c); /* also clears an index-map splat nobody will consume */
   if (r) return r;
   s->stats_pending = false;
   memset(&s->stats, 0, sizeof(s->stats));
@@ -1667,9 +1875,16 @@ extern "C" int suma_pipeline_minimize_hypotheses(suma_pipeline* s, const double*
   }
   c->icp_current = s->current_frame;
   c->icp_model = c->new_frame;
-  int r = suma_icp_minimize_batch(c, T0s, n_hyp, T_out, stats);
+  /* this path never runs update_pose, whose result record carries DevState: fetch it with the batch (the copy rides in
+   * front of the batch's own read-back and synchronisation), so that the map size the grids are sized from and the
+   * capacity / arena / time-out bits reach the host on every scan (round-3 advisor) */
+  hipError_t e = hipMemcpyAsync(c->h_ds, c->ds, sizeof(DevState), hipMemcpyDeviceToHost, c->stream);
+  int r = (e == hipSuccess) ? suma_icp_minimize_batch(c, T0s, n_hyp, T_out, stats) : SUMA_ERR_HIP;
   c->p = saved;
-  return r;
+  if (e != hipSuccess) c->err = std::string("hipMemcpyAsync(DevState): ") + hipGetErrorString(e);
+  if (r) return r;
+  c->known_surfels = c->h_ds->n_surfels;
+  return check_overflow(c);
 }
 /* the pose bookkeeping of updatePose (SurfelMapping.cpp:453-474) for an increment chosen by the caller */
 extern "C" int suma_pipeline_apply_increment(suma_pipeline* s, const double increment[16]) {

@@ -25,6 +25,9 @@
  */
 #include <string.h>
 
+#include <time.h>
+
+#include <atomic>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -63,33 +66,50 @@ struct CopySeg {
 };
 struct CopyPool {
   std::mutex mu;
-  std::condition_variable cv, done_cv;
+  std::condition_variable cv;
   std::vector<std::thread> th;
   CopySeg job[COPY_HELPERS][COPY_SEGMENTS];
-  uint64_t gen[COPY_HELPERS]; /* generation a helper has a job for */
-  uint64_t posted;
-  int pending;
-  bool stop;
+  /* A helper that went to sleep on the condition variable needs 30-60 us to run again, as long as the whole copy takes;
+   * scans arrive back to back, so a helper first SPINS on the generation word for SPIN_NS after its last job (and
+   * costs nothing once the caller stops sending scans: it then sleeps until the next post). */
+  std::atomic<uint64_t> posted;
+  std::atomic<int> pending;
+  std::atomic<int> sleepers;
+  std::atomic<bool> stop;
 };
+#define SPIN_NS 400000ll
+
+static long long mono_ns() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec;
+}
 
 static void copy_helper(CopyPool* p, int id) {
   uint64_t seen = 0;
+  long long idle_since = mono_ns();
   for (;;) {
-    CopySeg j[COPY_SEGMENTS];
-    {
+    uint64_t g = p->posted.load(std::memory_order_acquire);
+    if (g == seen) {
+      if (p->stop.load(std::memory_order_relaxed)) return;
+      if (mono_ns() - idle_since < SPIN_NS) {
+        __builtin_ia32_pause();
+        continue;
+      }
       std::unique_lock<std::mutex> lk(p->mu);
-      p->cv.wait(lk, [&] { return p->stop || p->gen[id] != seen; });
-      if (p->stop) return;
-      seen = p->gen[id];
-      for (int k = 0; k < COPY_SEGMENTS; ++k) j[k] = p->job[id][k];
+      p->sleepers.fetch_add(1);
+      p->cv.wait(lk, [&] { return p->stop.load() || p->posted.load(std::memory_order_acquire) != seen; });
+      p->sleepers.fetch_sub(1);
+      if (p->stop.load()) return;
+      continue;
     }
-    for (int k = 0; k < COPY_SEGMENTS; ++k)
-      if (j[k].bytes) memcpy(j[k].dst, j[k].src, j[k].bytes);
-    {
-      std::lock_guard<std::mutex> lk(p->mu);
-      p->pending -= 1;
+    seen = g;
+    for (int k = 0; k < COPY_SEGMENTS; ++k) {
+      const CopySeg j = p->job[id][k];
+      if (j.bytes) memcpy(j.dst, j.src, j.bytes);
     }
-    p->done_cv.notify_one();
+    p->pending.fetch_sub(1, std::memory_order_release);
+    idle_since = mono_ns();
   }
 }
 
@@ -103,35 +123,32 @@ static CopySeg seg_share(const CopySeg& s, int part) {
   return {s.dst + lo, s.src + lo, n};
 }
 
-/* every segment dst <- src, split over the helpers and the calling thread; one wake-up for the whole scan */
+/* every segment dst <- src, split over the helpers and the calling thread */
 static void pool_copy(CopyPool* p, const CopySeg* segs, int nseg) {
   size_t total = 0;
   for (int k = 0; k < nseg; ++k) total += segs[k].bytes;
-  if (total < (256u << 10) || p->th.empty()) {
+  if (total < (128u << 10) || p->th.empty()) {
     for (int k = 0; k < nseg; ++k)
       if (segs[k].bytes) memcpy(segs[k].dst, segs[k].src, segs[k].bytes);
     return;
   }
-  {
-    std::lock_guard<std::mutex> lk(p->mu);
-    p->posted += 1;
-    p->pending = COPY_HELPERS;
-    for (int h = 0; h < COPY_HELPERS; ++h) {
-      for (int k = 0; k < COPY_SEGMENTS; ++k) p->job[h][k] = (k < nseg) ? seg_share(segs[k], h + 1) : CopySeg{nullptr, nullptr, 0};
-      p->gen[h] = p->posted;
-    }
+  for (int h = 0; h < COPY_HELPERS; ++h)
+    for (int k = 0; k < COPY_SEGMENTS; ++k) p->job[h][k] = (k < nseg) ? seg_share(segs[k], h + 1) : CopySeg{nullptr, nullptr, 0};
+  p->pending.store(COPY_HELPERS, std::memory_order_relaxed);
+  p->posted.fetch_add(1, std::memory_order_release);
+  if (p->sleepers.load() > 0) {
+    std::lock_guard<std::mutex> lk(p->mu); /* pairs with the predicate check of a helper about to sleep */
+    p->cv.notify_all();
   }
-  p->cv.notify_all();
   for (int k = 0; k < nseg; ++k) {
     const CopySeg mine = seg_share(segs[k], 0);
     if (mine.bytes) memcpy(mine.dst, mine.src, mine.bytes);
   }
-  std::unique_lock<std::mutex> lk(p->mu);
-  p->done_cv.wait(lk, [&] { return p->pending == 0; });
+  while (p->pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
 }
 
 struct Ingest {
-  suma_pipeline* s;
+  suma_ctx* c;
   hipStream_t copy_stream;
   IngestSlot slot[INGEST_SLOTS];
   /* blocking entry (suma_pipeline_process_scan): two staging slots of its own, used alternately */
@@ -170,7 +187,7 @@ static hipError_t slot_reserve(Ingest* g, IngestSlot* q, uint32_t n) {
 }
 
 static void ingest_main(Ingest* g) {
-  hipSetDevice(g->s->c->device);
+  hipSetDevice(g->c->device);
   uint32_t next = 0; /* requests are served in order */
   for (;;) {
     IngestSlot* q;
@@ -209,15 +226,14 @@ static void ingest_main(Ingest* g) {
   }
 }
 
-static int ingest_get(suma_pipeline* s, Ingest** out) {
-  if (s->ingest) {
-    *out = s->ingest;
+static int ingest_get(suma_ctx* c, Ingest** out) {
+  if (c->ingest) {
+    *out = c->ingest;
     return SUMA_OK;
   }
-  suma_ctx* c = s->c;
   Ingest* g = new (std::nothrow) Ingest();
   if (!g) return SUMA_ERR_NOMEM;
-  g->s = s;
+  g->c = c;
   g->head = g->tail = 0;
   g->stop = false;
   for (auto& q : g->slot) {
@@ -227,8 +243,8 @@ static int ingest_get(suma_pipeline* s, Ingest** out) {
   g->bnext = 0;
   g->pool.posted = 0;
   g->pool.pending = 0;
+  g->pool.sleepers = 0;
   g->pool.stop = false;
-  for (int h = 0; h < COPY_HELPERS; ++h) g->pool.gen[h] = 0;
   HIP_TRY(c, hipStreamCreateWithFlags(&g->copy_stream, hipStreamNonBlocking));
   for (auto& q : g->slot) {
     HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
@@ -238,15 +254,19 @@ static int ingest_get(suma_pipeline* s, Ingest** out) {
     HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
   }
-  for (int h = 0; h < COPY_HELPERS; ++h) g->pool.th.emplace_back(copy_helper, &g->pool, h);
+  /* SUMA_COPY_HELPERS=0: the caller copies alone (hosts that cannot spare cores) */
+  const char* nh = getenv("SUMA_COPY_HELPERS");
+  const int helpers = nh ? atoi(nh) : COPY_HELPERS;
+  if (helpers > 0)
+    for (int h = 0; h < COPY_HELPERS; ++h) g->pool.th.emplace_back(copy_helper, &g->pool, h);
   g->worker = std::thread(ingest_main, g);
-  s->ingest = g;
+  c->ingest = g;
   *out = g;
   return SUMA_OK;
 }
 
-void ingest_destroy(suma_pipeline* s) {
-  Ingest* g = s ? s->ingest : nullptr;
+void ingest_destroy(suma_ctx* c) {
+  Ingest* g = c ? c->ingest : nullptr;
   if (!g) return;
   {
     std::lock_guard<std::mutex> lk(g->mu);
@@ -276,14 +296,31 @@ void ingest_destroy(suma_pipeline* s) {
   }
   hipStreamDestroy(g->copy_stream);
   delete g;
-  s->ingest = nullptr;
+  c->ingest = nullptr;
+}
+
+/* scans staged ahead of their turn that nobody will process (a failed sequence, suma_pipeline_reset): wait for their
+ * uploads and mark the slots free, so that the next sequence on this pipeline does not consume them (round-3 advisor) */
+void ingest_drain(suma_ctx* c) {
+  Ingest* g = c ? c->ingest : nullptr;
+  if (!g) return;
+  std::unique_lock<std::mutex> lk(g->mu);
+  while (g->head != g->tail) {
+    IngestSlot* q = &g->slot[g->head % INGEST_SLOTS];
+    g->cv.wait(lk, [&] { return q->state == 2 || q->state == -1; });
+    q->state = 0;
+    g->head += 1;
+  }
+  lk.unlock();
+  hipStreamSynchronize(g->copy_stream);
+  for (auto& q : g->slot) q.consumed_valid = false;
 }
 
 extern "C" int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* points, const float* labels,
                                            const float* probs, uint32_t n) {
   if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
   Ingest* g = nullptr;
-  int r = ingest_get(s, &g);
+  int r = ingest_get(s->c, &g);
   if (r) return r;
   std::lock_guard<std::mutex> lk(g->mu);
   if (g->tail - g->head >= INGEST_SLOTS) {
@@ -303,9 +340,14 @@ extern "C" int suma_pipeline_prefetch_scan(suma_pipeline* s, const suma_float4* 
 
 /* the oldest staged scan: begin (phases_only) or the whole scan */
 static int run_prefetched(suma_pipeline* s, int32_t fixed_iterations, bool begin_only) {
-  if (!s || !s->ingest) return SUMA_ERR_INVALID;
-  Ingest* g = s->ingest;
+  if (!s || !s->c->ingest) return SUMA_ERR_INVALID;
+  Ingest* g = s->c->ingest;
   suma_ctx* c = s->c;
+  /* the phase is checked BEFORE a slot is taken: a call in the wrong phase must not drop a staged scan */
+  if (s->phase != 0) {
+    c->err = "suma_pipeline_process_prefetched: the previous scan has not been closed with suma_pipeline_update_map";
+    return SUMA_ERR_INVALID;
+  }
   IngestSlot* q;
   {
     std::unique_lock<std::mutex> lk(g->mu);
@@ -353,8 +395,8 @@ extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_flo
                                                 const float* probs, uint32_t n, int32_t fixed_iterations) {
   if (!s || (n > 0 && !points)) return SUMA_ERR_INVALID;
   bool staged = false;
-  if (s->ingest) {
-    Ingest* g = s->ingest;
+  if (s->c->ingest) {
+    Ingest* g = s->c->ingest;
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->head != g->tail) {
       const IngestSlot& q = g->slot[g->head % INGEST_SLOTS];
@@ -372,20 +414,21 @@ extern "C" int suma_pipeline_process_scan_async(suma_pipeline* s, const suma_flo
   return suma_pipeline_process_prefetched(s, fixed_iterations);
 }
 
-/* SurfelMapping::processScan with host vectors, as the reference's caller hands them over (SurfelMapping.cpp:175-210):
- * the scan is copied into pinned memory by the caller and COPY_HELPERS helper threads, uploaded on the copy stream, and
- * the preprocessing waits for the upload on the device -- the call returns as early as the device-pointer entry does,
- * so the surfel passes of this scan overlap the next call's copy. */
-static int run_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
-                         int32_t fixed_iterations, bool begin_only) {
+/* A pageable host scan on its way to the device, on the CALLER's time line: the scan is copied into one of two pinned
+ * blocks by the caller and the helper threads and uploaded on the copy stream, both in HOST_CHUNKS pieces -- the DMA of
+ * piece k runs while piece k + 1 is being copied, so the scan is on the device about one piece after its last byte
+ * was copied.  Returns the device pointers and the event the consumer stream must wait for; the caller hands the slot
+ * back with ingest_consumed once the reader has been enqueued. */
+int ingest_stage_blocking(suma_ctx* c, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                          const suma_float4** d_points, const float** d_labels, const float** d_probs, hipEvent_t* uploaded,
+                          void** slot) {
   Ingest* g = nullptr;
-  int r = ingest_get(s, &g);
+  int r = ingest_get(c, &g);
   if (r) return r;
-  suma_ctx* c = s->c;
   {
     std::lock_guard<std::mutex> lk(g->mu);
     if (g->head != g->tail) {
-      c->err = "suma_pipeline_process_scan: prefetched scans are waiting (suma_pipeline_process_prefetched comes first)";
+      c->err = "host scan while prefetched scans are waiting (suma_pipeline_process_prefetched comes first)";
       return SUMA_ERR_INVALID;
     }
   }
@@ -393,24 +436,9 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
   if (q->consumed_valid) HIP_TRY(c, hipEventSynchronize(q->consumed)); /* the scan before last has read this slot */
   HIP_TRY(c, slot_reserve(g, q, n));
   if (n > 0) {
-    CopySeg segs[COPY_SEGMENTS];
-    int nseg = 0;
     size_t bytes = (size_t)n * sizeof(float4);
-    segs[nseg++] = {q->pinned, (const char*)points, (size_t)n * sizeof(float4)};
-    if (labels) {
-      segs[nseg++] = {q->pinned + labels_offset(n), (const char*)labels, (size_t)n * sizeof(float)};
-      bytes = labels_offset(n) + (size_t)n * sizeof(float);
-    }
-    if (probs) {
-      segs[nseg++] = {q->pinned + probs_offset(n), (const char*)probs, (size_t)n * sizeof(float)};
-      bytes = probs_offset(n) + (size_t)n * sizeof(float);
-    }
-    /* The pinned copy and the PCIe transfer are pipelined in HOST_CHUNKS pieces: the DMA of piece k runs while the
-     * caller and the helpers copy piece k + 1, so the scan is on the device ~one piece after the last byte has been
-     * copied (one copy + one transfer back to back took about as long as the GPU work queued behind the previous
-     * call, and the preprocessing waited for the rest) */
-    (void)segs;
-    (void)nseg;
+    if (labels) bytes = labels_offset(n) + (size_t)n * sizeof(float);
+    if (probs) bytes = probs_offset(n) + (size_t)n * sizeof(float);
     const size_t piece = ((bytes / HOST_CHUNKS) + 4095) & ~(size_t)4095;
     /* the staging layout is points | labels | probs at fixed offsets: walk it piece by piece, copying from whichever
      * source arrays overlap the piece */
@@ -433,9 +461,33 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
     }
   }
   HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
-  r = pipeline_begin_scan_impl(s, (const suma_float4*)q->device, labels ? (const float*)(q->device + labels_offset(n)) : nullptr,
-                               probs ? (const float*)(q->device + probs_offset(n)) : nullptr, n, q->uploaded);
-  q->consumed_valid = (hipEventRecord(q->consumed, pipeline_input_stream(s)) == hipSuccess);
+  *d_points = (const suma_float4*)q->device;
+  *d_labels = labels ? (const float*)(q->device + labels_offset(n)) : nullptr;
+  *d_probs = probs ? (const float*)(q->device + probs_offset(n)) : nullptr;
+  *uploaded = q->uploaded;
+  *slot = (void*)q;
+  return SUMA_OK;
+}
+void ingest_consumed(suma_ctx* c, void* slot, hipStream_t reader) {
+  IngestSlot* q = (IngestSlot*)slot;
+  (void)c;
+  q->consumed_valid = (hipEventRecord(q->consumed, reader) == hipSuccess);
+}
+
+/* SurfelMapping::processScan with host vectors, as the reference's caller hands them over (SurfelMapping.cpp:175-210):
+ * staged as above, the preprocessing waits for the upload on the device -- the call returns as early as the
+ * device-pointer entry does, so the surfel passes of this scan overlap the next call's copy. */
+static int run_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                         int32_t fixed_iterations, bool begin_only) {
+  suma_ctx* c = s->c;
+  const suma_float4* dp;
+  const float *dl, *dq;
+  hipEvent_t up;
+  void* slot;
+  int r = ingest_stage_blocking(c, points, labels, probs, n, &dp, &dl, &dq, &up, &slot);
+  if (r) return r;
+  r = pipeline_begin_scan_impl(s, dp, dl, dq, n, up);
+  ingest_consumed(c, slot, pipeline_input_stream(s));
   if (r == SUMA_OK && !begin_only) {
     r = pipeline_update_pose_impl(s, fixed_iterations);
     if (r == SUMA_OK) r = pipeline_update_map_impl(s);

@@ -76,7 +76,12 @@ struct HostResult {
   uint32_t valid, outlier, invalid, k, converged, iteration;
   DevState ds;
   uint32_t seq;
-  uint32_t pad;
+  uint32_t n_hist;
+  /* only filled for the class-by-class entries (suma_icp_minimize / suma_icp_jacobian_products), not by the scan
+   * pipeline's launches: the fixed-point sums of the last step with the bias removed (JtJ / Jtr / F are these words
+   * times 2^-28, formed on the host exactly as the device forms them) */
+  int64_t acc[SUMA_ACC_WORDS];
+  double JtJ[36], Jtr[6]; /* of the last step (LieGaussNewton::information); closing launch of suma_icp_minimize only */
 };
 
 struct MapConsts {
@@ -88,6 +93,12 @@ struct suma_frame {
   suma_ctx* ctx;
   uint32_t width, height;
   float4* map[3]; /* vertex, normal, semantic: one allocation */
+  /* bumped by every call of the C-ABI that writes the frame (upload / copy / swap / preprocess / render / touch): what
+   * the render de-duplication and the fused K8 products compare instead of assuming that a caller-owned frame changed */
+  uint64_t version;
+  /* ctx-stream accesses (suma_ctx.enq_seq) -- lets suma_preprocess put its side-stream work in front of everything
+   * the ctx stream still holds, unless that includes an access to this very frame */
+  uint64_t last_access;
 };
 
 struct ProfEvent {
@@ -103,10 +114,22 @@ struct suma_ctx {
   int device;
   hipStream_t stream;      /* the ctx stream: everything the C-ABI promises to order */
   hipStream_t ls;          /* stream the launchers enqueue on: == stream, except while the scan pipeline enqueues side work */
-  hipStream_t side_stream; /* scan pipeline only: work that is off the critical path of a scan (next scan's preprocessing) */
+  hipStream_t side_stream; /* work that is off the critical path of a scan (the next scan's upload + preprocessing) */
+  int side_stream_off;     /* SUMA_NO_SIDE_STREAM / a serialising tool: everything on the ctx stream */
   uint32_t* sync_flags;    /* device: sequence words of the in-memory stream hand-offs (k_sync.hip) */
   uint32_t pre_seq;        /* preprocessing hand-offs issued so far */
   uint32_t gate_pending;   /* != 0: the ctx stream has not yet waited for this preprocessing hand-off (flush_gate) */
+  int gate_by_event;       /* the pending hand-off is a runtime event (pre_event), not the in-memory word: several
+                              pipelines in one process, see side_handoff (k_sync.hip) */
+  hipEvent_t pre_event;
+  hipEvent_t order_event;  /* ctx stream -> side stream, only when a frame's last access may still be in flight */
+  uint64_t enq_seq, done_seq; /* frame accesses enqueued on the ctx stream / known complete at the last host wait */
+  bool cache_nothing_stale; /* the last compaction attempt found no stale block: no point in synchronising again */
+  const suma_frame* gate_frame; /* the frame the pending side-stream work writes */
+  struct Ingest* ingest;   /* pinned double-buffered scan staging + copy stream + helper threads (suma_ingest.hip) */
+  HostResult* h_rec;       /* pinned: results of suma_icp_minimize / suma_icp_jacobian_products ([0] / [1]) */
+  uint32_t rec_seq;
+  int gn_host_full;        /* the reporting launch being enqueued also writes HostResult.acc / n_hist */
   std::string err;
 
   proj_t pd, pm; /* data / model projection */
@@ -138,6 +161,7 @@ struct suma_ctx {
   uint32_t gn_launch;  /* launches since the last gn_init */
   /* per-pixel K8 products already written for (frame, stamp) by the statistics pass, see launch_map_update */
   const suma_frame* k8_fused_frame;
+  uint64_t k8_fused_version; /* suma_frame.version the products were made from */
   uint32_t k8_fused_stamp;
   uint64_t k8_fused_params;
   int gn_fuse_k8; /* the next eval-only pixel launch also runs K8's per-pixel work and the counter resets */
@@ -153,6 +177,7 @@ struct suma_ctx {
   double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
   double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
   uint32_t gn_history_cap;
+  uint32_t last_n_hist; /* LieGaussNewton::history() entries of the last suma_icp_minimize */
   uint32_t icp_blocks;
   GnState* h_gn; /* pinned */
 
@@ -215,11 +240,21 @@ struct suma_ctx {
     float pose[16];
     uint64_t map_version, params_version;
   } k7;
+  /* suma_map_render_active splats the index map speculatively (the reference's updatePose renders the active map at
+   * the pose that updateMap then passes to update(), SurfelMapping.cpp:406 / :799); a splat nobody consumed switches the
+   * speculation off until an update arrives that WOULD have consumed one */
+  struct {
+    bool on;
+    bool have_last;
+    float last_pose[16];
+    uint64_t map_version, params_version;
+  } k7_spec;
   struct {
     bool valid;
     float pose_old[16], pose_new[16], conf_threshold;
     uint64_t map_version, params_version;
     const suma_frame* out;
+    uint64_t out_version, old_version, new_version; /* suma_frame.version of the three targets after the render */
   } rendered;
 };
 
@@ -240,7 +275,6 @@ struct suma_pipeline {
   bool stats_pending;
   uint32_t stats_slot;
   suma_icp_stats stats_mst;
-  struct Ingest* ingest; /* pinned double-buffered scan staging + copy stream + ingest thread (suma_ingest.hip) */
 };
 
 int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
@@ -252,7 +286,19 @@ int pipeline_update_map_impl(suma_pipeline* s);
 /* the stream behind which a scan's input buffers are free again (the preprocessing that read them runs there) */
 hipStream_t pipeline_input_stream(suma_pipeline* s);
 /* suma_ingest.hip */
-void ingest_destroy(suma_pipeline* s);
+void ingest_destroy(suma_ctx* c);
+void ingest_drain(suma_ctx* c);
+/* host scan -> pinned staging -> copy stream; *d_base = device block (points | labels | probs), *uploaded = the event the
+ * consumer stream waits for, *slot = token for ingest_consumed */
+int ingest_stage_blocking(suma_ctx* c, const suma_float4* points, const float* labels, const float* probs, uint32_t n,
+                          const suma_float4** d_points, const float** d_labels, const float** d_probs, hipEvent_t* uploaded,
+                          void** slot);
+void ingest_consumed(suma_ctx* c, void* slot, hipStream_t reader);
+/* side stream of a ctx (created on first use; NULL under SUMA_NO_SIDE_STREAM / serialising tools) */
+int ensure_side_stream(suma_ctx* c);
+/* after side-stream work that writes `frame`: the ctx stream's next reader waits for it (flush_gate) */
+int side_handoff(suma_ctx* c, const suma_frame* frame);
+void side_stream_released(suma_ctx* c);
 int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,
                                uint32_t n, int32_t fixed_iterations);
 

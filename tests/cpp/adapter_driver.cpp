@@ -42,8 +42,8 @@ int main(int argc, char** argv) {
     auto current = std::make_shared<suma_hip::Frame>(ctx, width, 64);
     auto last = std::make_shared<suma_hip::Frame>(ctx, width, 64);
     suma_hip::Frame model(ctx, width, 64);
-    double pose[16], increment[16];
-    for (int i = 0; i < 16; ++i) pose[i] = increment[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    double pose[16], increment[16], increment_before[16];
+    for (int i = 0; i < 16; ++i) pose[i] = increment[i] = increment_before[i] = (i % 5 == 0) ? 1.0 : 0.0;
     for (int k = 0; k < n_scans; ++k) {
       char path[4096];
       std::snprintf(path, sizeof(path), "%s/%06d.bin", dir, k);
@@ -88,7 +88,51 @@ int main(int argc, char** argv) {
       }
       std::printf(" %u %u %u %u %u %s\n", map.size(), objective.valid(), objective.outlier(), fb_outlier,
                   map.getDataSurfels().n, gn.reason(0).c_str());
+      if (k > 0) { /* LieGaussNewton::history(): fetched lazily; entry 0 is the start pose, the last one the result of `recovery` */
+        const std::vector<double>& h = gn.history();
+        if (h.size() < 32 || h.size() % 16 != 0) return 5;
+        for (int i = 0; i < 16; ++i)
+          if (h[i] != increment_before[i] || h[h.size() - 16 + i] != gn.pose()[i]) return 6;
+      }
+      std::memcpy(increment_before, increment, sizeof(increment));
     }
+    /* ---- SurfelMapping::Stats (SurfelMapping.cpp:183-207, 393-394): the keys the untouched GUI plots ---- */
+    suma_hip::SurfelMapping sm(p, 0);
+    auto nop = [](suma_hip::SurfelMapping&) {};
+    for (int k = 0; k < n_scans; ++k) {
+      char path[4096];
+      std::snprintf(path, sizeof(path), "%s/%06d.bin", dir, k);
+      FILE* f = std::fopen(path, "rb");
+      if (!f) return 3;
+      std::fseek(f, 0, SEEK_END);
+      const size_t n = (size_t)std::ftell(f) / sizeof(suma_float4);
+      std::fseek(f, 0, SEEK_SET);
+      std::vector<suma_float4> pts(n);
+      if (std::fread(pts.data(), sizeof(suma_float4), n, f) != n) return 4;
+      std::fclose(f);
+      if (k & 1)
+        sm.processScan(pts.data(), nullptr, nullptr, (uint32_t)n, nop, nop, 0);
+      else
+        sm.processScan(pts.data(), nullptr, nullptr, (uint32_t)n, 0); /* the one-argument form fills them too */
+      const std::map<std::string, double>& st = sm.getStatistics();
+      const char* always[] = {"initialize-time", "preprocessing-time", "mapping-time", "map-update", "complete-time", "icp_percentage"};
+      const char* tracked[] = {"icp-time", "opt-time", "icp-overall", "loop-time", "num_iterations"};
+      for (const char* key : always)
+        if (!st.count(key)) { std::fprintf(stderr, "missing statistics key %s\n", key); return 7; }
+      if (k > 0) {
+        for (const char* key : tracked)
+          if (!st.count(key)) { std::fprintf(stderr, "missing statistics key %s\n", key); return 7; }
+        const double it = st.at("num_iterations"), icp = st.at("icp-time"), all = st.at("complete-time");
+        if (!(it >= 1.0 && it <= (double)p.max_iterations)) return 8;
+        if (!(icp > 0.0 && icp <= all && all < 5.0)) return 9;
+        if (!(st.at("icp_percentage") > 0.0 && st.at("icp_percentage") <= 1.0)) return 10;
+        if (!(st.at("mapping-time") > 0.0 && st.at("preprocessing-time") > 0.0)) return 11;
+      } else if (st.count("icp-time")) {
+        return 12; /* updatePose does not run on the first scan (SurfelMapping.cpp:190) */
+      }
+    }
+    std::printf("statistics ok: icp-time %.6f s, complete-time %.6f s, num_iterations %.0f\n", sm.getStatistics().at("icp-time"),
+                sm.getStatistics().at("complete-time"), sm.getStatistics().at("num_iterations"));
   } catch (const std::exception& e) {
     std::fprintf(stderr, "adapter_driver: %s\n", e.what());
     return 1;

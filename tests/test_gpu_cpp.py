@@ -54,6 +54,8 @@ def build(hip, tmp, src, lang):
 def test_cpp_adapter_runs_the_reference_call_sequence(hip, scan_dir, tmp_path):
     exe = build(hip, str(tmp_path), os.path.join(ROOT, "tests", "cpp", "adapter_driver.cpp"), "c++")
     out = subprocess.check_output([exe, scan_dir, str(N), str(W)], timeout=120).decode().strip().splitlines()
+    assert out[-1].startswith("statistics ok"), out[-1]  # SurfelMapping::Stats keys of suma_hip::SurfelMapping
+    out = out[:-1]
     assert len(out) == N
     # the same sequence through the ctypes mirror classes
     p = params_with_size(W, max_iterations=10, label_offset=0, prob_offset=0)
