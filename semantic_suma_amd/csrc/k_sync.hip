@@ -13,6 +13,7 @@
  * arrives surfaces as DevState.overflow bit 3 (SUMA_ERR_HIP), never as a hung GPU.
  */
 #include <atomic>
+#include <cstddef>
 #include <cstdlib>
 
 #include "suma_internal.h"
@@ -29,6 +30,7 @@ __global__ void k_gate(const uint32_t* word, uint32_t seq, uint32_t* fault) {
     __builtin_amdgcn_s_sleep(16);
   }
   atomicOr(fault, 8u);
+  atomicOr(fault + (offsetof(DevState, fault_site) - offsetof(DevState, overflow)) / 4, 0x1u); /* the stream gate */
 }
 
 hipError_t launch_signal(suma_ctx* c, hipStream_t st, uint32_t word, uint32_t seq) {

@@ -1211,7 +1211,11 @@ extern "C" int suma_map_update_poses(suma_ctx* c, const float* poses16, uint32_t
 static int check_overflow(suma_ctx* c) {
   if (c->h_ds->overflow & 1u) return fail(c, SUMA_ERR_CAPACITY, "surfel capacity (max_surfels) exceeded; map truncated");
   if (c->h_ds->overflow & 2u) return fail(c, SUMA_ERR_CAPACITY, "submap cache arena (cache_surfels) exhausted");
-  if (c->h_ds->overflow & 8u) return fail(c, SUMA_ERR_HIP, "stable-compaction hand-off timed out (internal error)");
+  if (c->h_ds->overflow & 8u) {
+    char msg[160];
+    snprintf(msg, sizeof(msg), "stable-compaction / stream hand-off timed out (internal error, site mask 0x%x)", c->h_ds->fault_site);
+    return fail(c, SUMA_ERR_HIP, msg);
+  }
   return SUMA_OK;
 }
 
