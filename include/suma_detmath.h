@@ -30,6 +30,16 @@
 #define SUMA_HD static inline
 #endif
 
+/* One multiply-add step of a polynomial kernel.  The SPECIFICATION is the unfused form -- two roundings, (a * b) + c --
+ * on every side (oracle, compiled reference shaders, gfx950 kernels).  -DSUMA_DETMATH_FMA builds the fused form for the
+ * timing experiment of round 4 only (tools/build_variant.sh: what would explicit fmaf steps inside these kernels buy?
+ * DESIGN.md section 4): such a build is NOT bit-compatible with the oracle and is never shipped. */
+#ifdef SUMA_DETMATH_FMA
+#define SDM_MA(a, b, c) __builtin_fmaf((a), (b), (c))
+#else
+#define SDM_MA(a, b, c) (((a) * (b)) + (c))
+#endif
+
 #define SUMA_PI_F 3.14159265358979323846f
 #define SUMA_PI_2_F 1.57079632679489661923f
 #define SUMA_PI_4_F 0.78539816339744830962f
@@ -80,10 +90,10 @@ SUMA_HD float sdm_atan(float xx) {
     y = 0.0f;
   }
   float z = x * x;
-  float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
-  p = p * z + 1.99777106478e-1f;
-  p = p * z - 3.33329491539e-1f;
-  p = p * z * x + x;
+  float p = SDM_MA(8.05374449538e-2f, z, -1.38776856032e-1f);
+  p = SDM_MA(p, z, 1.99777106478e-1f);
+  p = SDM_MA(p, z, -3.33329491539e-1f);
+  p = SDM_MA(p * z, x, x);
   y = y + p;
   return (xx < 0.0f) ? -y : y;
 }
@@ -125,11 +135,11 @@ SUMA_HD float sdm_asin(float xx) {
     x = a;
     z = x * x;
   }
-  float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
-  p = p * z + 4.5470025998e-2f;
-  p = p * z + 7.4953002686e-2f;
-  p = p * z + 1.6666752422e-1f;
-  z = p * z * x + x;
+  float p = SDM_MA(4.2163199048e-2f, z, 2.4181311049e-2f);
+  p = SDM_MA(p, z, 4.5470025998e-2f);
+  p = SDM_MA(p, z, 7.4953002686e-2f);
+  p = SDM_MA(p, z, 1.6666752422e-1f);
+  z = SDM_MA(p * z, x, x);
   if (flag) {
     z = z + z;
     z = SUMA_PI_2_F - z;
@@ -172,15 +182,15 @@ SUMA_HD float sdm_sincos_core(float xx, int want_cos) {
   float r;
   int use_cos_poly = want_cos ? !(j == 1 || j == 2) : (j == 1 || j == 2);
   if (use_cos_poly) {
-    float p = 2.443315711809948e-5f * z - 1.388731625493765e-3f;
-    p = p * z + 4.166664568298827e-2f;
+    float p = SDM_MA(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+    p = SDM_MA(p, z, 4.166664568298827e-2f);
     r = p * z * z;
     r = r - 0.5f * z;
     r = r + 1.0f;
   } else {
-    float p = -1.9515295891e-4f * z + 8.3321608736e-3f;
-    p = p * z - 1.6666654611e-1f;
-    r = p * z * x + x;
+    float p = SDM_MA(-1.9515295891e-4f, z, 8.3321608736e-3f);
+    p = SDM_MA(p, z, -1.6666654611e-1f);
+    r = SDM_MA(p * z, x, x);
   }
   return (sign < 0) ? -r : r;
 }
@@ -213,12 +223,12 @@ SUMA_HD float sdm_exp(float xx) {
   x = x - z * C2;
   int32_t n = (int32_t)z;
   z = x * x;
-  float p = 1.9875691500e-4f * x + 1.3981999507e-3f;
-  p = p * x + 8.3334519073e-3f;
-  p = p * x + 4.1665795894e-2f;
-  p = p * x + 1.6666665459e-1f;
-  p = p * x + 5.0000001201e-1f;
-  z = p * z + x + 1.0f;
+  float p = SDM_MA(1.9875691500e-4f, x, 1.3981999507e-3f);
+  p = SDM_MA(p, x, 8.3334519073e-3f);
+  p = SDM_MA(p, x, 4.1665795894e-2f);
+  p = SDM_MA(p, x, 1.6666665459e-1f);
+  p = SDM_MA(p, x, 5.0000001201e-1f);
+  z = SDM_MA(p, z, x) + 1.0f;
   return sdm_ldexp(z, n);
 }
 
@@ -244,14 +254,14 @@ SUMA_HD float sdm_log(float xx) {
     x = x - 1.0f;
   }
   float z = x * x;
-  float p = 7.0376836292e-2f * x - 1.1514610310e-1f;
-  p = p * x + 1.1676998740e-1f;
-  p = p * x - 1.2420140846e-1f;
-  p = p * x + 1.4249322787e-1f;
-  p = p * x - 1.6668057665e-1f;
-  p = p * x + 2.0000714765e-1f;
-  p = p * x - 2.4999993993e-1f;
-  p = p * x + 3.3333331174e-1f;
+  float p = SDM_MA(7.0376836292e-2f, x, -1.1514610310e-1f);
+  p = SDM_MA(p, x, 1.1676998740e-1f);
+  p = SDM_MA(p, x, -1.2420140846e-1f);
+  p = SDM_MA(p, x, 1.4249322787e-1f);
+  p = SDM_MA(p, x, -1.6668057665e-1f);
+  p = SDM_MA(p, x, 2.0000714765e-1f);
+  p = SDM_MA(p, x, -2.4999993993e-1f);
+  p = SDM_MA(p, x, 3.3333331174e-1f);
   float y = p * x * z;
   float fe = (float)e;
   y = y + -2.12194440e-4f * fe;

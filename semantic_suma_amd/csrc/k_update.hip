@@ -61,7 +61,6 @@ __device__ __forceinline__ void lookback_publish(unsigned long long* __restrict_
  * Every spin is bounded (SUMA_SPIN_LIMIT polls, seconds of wall time): a protocol error must surface
  * as an error code (DevState.overflow bit 3), never as a hung GPU. */
 #define SUMA_SPIN_LIMIT (1u << 26)
-template <bool SLEEP = false> /* SLEEP: the poller shares its CU with waves that have work to do (k9_update_w) */
 __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
                                      uint32_t tile, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
   const uint32_t g = tile >> 6;
@@ -74,7 +73,6 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
     for (;;) {
       w = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if ((uint32_t)(w >> 32) == 64u || ++spins >= SUMA_SPIN_LIMIT) break;
-      if (SLEEP) __builtin_amdgcn_s_sleep(8);
     }
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
@@ -87,7 +85,6 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
     for (;;) {
       w = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (!((uint32_t)(w >> 34) != (epoch & 0x3fffffffu) || ((w >> 32) & 3ull) == 0) || ++spins >= SUMA_SPIN_LIMIT) break;
-      if (SLEEP) __builtin_amdgcn_s_sleep(8);
     }
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
@@ -473,7 +470,11 @@ __device__ __forceinline__ bool k9_finish(const UpdArgs& a, uint32_t i, const Su
  *    computed and published -- by then the words are almost always there (waiting right after the compute
  *    exposes each block to the slowest of the ~256 tiles in flight ahead of it);
  *  - the barriers are LDS-only (no vmcnt drain): the fire-and-forget stores (integration mask, status
- *    words, the previous tile's stream-out) stay in flight across them. */
+ *    words, the previous tile's stream-out) stay in flight across them.
+ * Round 4 built the same kernel WITHOUT block barriers (every wave owns its 64 surfels from load to stream-out, counts
+ * and offsets exchanged through polled LDS words; git log -S k9_update_w): bit-identical and slower, 88 us against 76 --
+ * a tile's total cannot be published before its slowest wave has reported, so the drift the barriers prevent comes
+ * back one for one as look-back wait of every later tile (profiles/r04_k9_wave_independent_experiment.txt). */
 #ifndef K9_PER
 #define K9_PER 1 /* surfels per lane (see above) */
 #endif
@@ -672,258 +673,6 @@ __global__ void __launch_bounds__(K9_THREADS)
   if (is_finaliser(s_tile, ntiles)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
     if (threadIdx.x == 0 && ntiles == 0) a.ds->n_kept_updated = 0;
-  }
-}
-
-/* ---------------------------------------------------------------------------------------------
- * K9, wave-independent form (round 4; the default -- SUMA_K9_BLOCK=1 selects the block-cooperative kernel above)
- * ---------------------------------------------------------------------------------------------
- * The block-cooperative kernel walks every tile of 1024 surfels in lock step: sixteen waves meet at five barriers
- * per tile, and the phase timeline (profiles/r03_phase_timeline.txt) shows what that costs -- 31 % of a block's time is
- * the wait for the slowest of the sixteen waves (divergent update arithmetic, one late gather), 12 % the ticket between
- * two barriers, 14 % the look-back behind another one; nothing overlaps inside a CU because all its waves are always in
- * the same phase.  Here a wave owns its 64 surfels of the block's tile from load to stream-out:
- *   - it loads, updates and ranks them on its own (ballots), drops the records into its PRIVATE 2 x 4 KB of LDS, reports
- *     its count in an LDS word, and -- one tile later -- streams the records out at
- *         (surfels emitted by all earlier tiles) + (counts of the lower waves of its own tile);
- *     there is no __syncthreads in the loop: the sixteen waves of a CU drift apart and fill each other's memory round
- *     trips, and a wave waits (polling LDS) only for what it really needs, one tile late, when it is almost always there;
- *   - between blocks nothing changes: tickets per 1024-surfel tile, the tile's total published as status word + group
- *     accumulator, two-level look-back (lookback_publish / lookback_collect above).  The total is published by whichever
- *     wave reports last; the look-back of a tile is collected once, by the first wave that needs it, and shared through
- *     LDS.  (A first version published per WAVE-tile with a three-level look-back: bit-identical and 7 x slower -- 16 k
- *     publishers and pollers on a few dozen accumulator words serialise at their memory channel.)
- *   - wave 0 draws the block's next ticket one round ahead and hands it over through a four-slot LDS ring; a slot is
- *     reused only when all sixteen waves are through with the round that used it last.  Every wave reports before it
- *     waits and tiles are taken in ticket order, so the smallest unpublished tile never waits on anything: no circular
- *     wait; all spins are bounded (DevState.overflow bit 3 + fault_site);
- *   - the block that finishes LAST (a counter in DevState) re-arms the ticket and clears the accumulators of the next
- *     launch: with tickets drawn one round ahead "largest failing ticket" no longer implies "everybody else is done". */
-#define K9W_WAVES 16
-#define K9W_THREADS (64 * K9W_WAVES)
-#define K9W_RING 4
-
-/* LDS words shared between the waves of a block without a barrier */
-__device__ __forceinline__ uint32_t lds_load(const uint32_t* p) {
-  return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store(uint32_t* p, uint32_t v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-/* the compiler must not move one lane's LDS accesses across another lane's (the hardware runs a wave's LDS
- * traffic in order; no instruction is emitted) */
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-/* wave-uniform wait until *p == want; false after SUMA_SPIN_LIMIT polls */
-__device__ __forceinline__ bool lds_wait_eq(const uint32_t* p, uint32_t want) {
-  uint32_t spins = 0;
-  while (lds_load(p) != want) {
-    if (++spins >= SUMA_SPIN_LIMIT) return false;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  return true;
-}
-__device__ __forceinline__ void k9w_fault(DevState* ds, uint32_t site, int lane) {
-  if (lane == 0) {
-    atomicOr(&ds->overflow, 8u);
-    atomicOr(&ds->fault_site, site);
-  }
-}
-
-__global__ void __launch_bounds__(K9W_THREADS) k9_update_w(UpdArgs a) {
-  __shared__ float4 s_out[K9W_WAVES][2][64][4]; /* a wave's updated records at their uncompacted slot, double buffered */
-  __shared__ uint8_t s_slot[K9W_WAVES][2][64];  /* stable rank -> slot */
-  __shared__ uint8_t s_ext[K9W_WAVES][2][64];   /* slot -> "in the tile that is extracted after this update" */
-  /* per round (ring slot): the tile, and what the waves tell each other about it */
-  __shared__ uint32_t s_tag[K9W_RING], s_tile[K9W_RING], s_tclaim[K9W_RING]; /* ticket hand-over: tag = round */
-  __shared__ uint32_t s_cnt[K9W_RING][K9W_WAVES];         /* (round + 1) << 8 | surfels emitted by the wave */
-  __shared__ uint32_t s_arrived[K9W_RING];                /* waves that have reported */
-  __shared__ uint32_t s_claim[K9W_RING], s_pref[K9W_RING], s_pref_tag[K9W_RING]; /* the tile's global prefix, collected once */
-  __shared__ uint32_t s_finished[K9W_RING];               /* waves that are through with the round (stream-out issued) */
-  __shared__ uint32_t s_keep, s_done;
-  const uint32_t S = a.ds->n_surfels;
-  const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
-  const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
-  float4* __restrict__ dst4 = reinterpret_cast<float4*>(a.out);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < K9W_RING) {
-    s_tag[threadIdx.x] = 0xffffffffu;
-    s_pref_tag[threadIdx.x] = 0xffffffffu;
-    /* monotone counters, never reset: the k-th use of a slot (round = 4 k + slot) finds 16 k in s_arrived /
-     * s_finished and claims with the value round + 1 */
-    s_finished[threadIdx.x] = 0;
-    s_arrived[threadIdx.x] = 0;
-    s_claim[threadIdx.x] = 0;
-    s_tclaim[threadIdx.x] = 0;
-  }
-  if (threadIdx.x < K9W_RING * K9W_WAVES) (&s_cnt[0][0])[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {
-    s_keep = 0;
-    s_done = 0;
-    if (a.write_pose && blockIdx.x == 0) write_pose_entry(a.poses_w, a.poses_inv_w, a.pose_idx, a.pose);
-  }
-  __syncthreads(); /* the only block barrier of the kernel */
-  uint32_t kept_sum = 0; /* survivors before the area filter (S'), wave-uniform */
-  uint32_t prev_tile = 0xffffffffu, prev_total = 0, buf = 0;
-  bool prev_has = false;
-  PH_BEGIN;
-  for (uint32_t round = 0;; ++round) {
-    PH(7);
-    const uint32_t rs = round & (K9W_RING - 1u);
-    /* ---- this round's tile: drawn by the FIRST wave of the block that needs it (tile order = the order in which
-     *      tiles start, as in the block-cooperative kernel; a ticket drawn a round ahead puts tiles that start late in
-     *      front of tiles that start early, and every later tile's look-back waits for them: measured 107 us) ---- */
-    uint32_t tile = 0xffffffffu;
-    if (lds_load(&s_tag[rs]) != round) {
-      uint32_t before = round + 1u;
-      if (lane == 0) before = __hip_atomic_fetch_max(&s_tclaim[rs], round + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-      if (before < round + 1u) { /* mine to draw; the slot is free once all waves are through with round - 4 */
-        if (!lds_wait_eq(&s_finished[rs], K9W_WAVES * (round >> 2))) k9w_fault(a.ds, 0x40u, lane);
-        if (lane == 0) {
-          s_tile[rs] = __hip_atomic_fetch_add(&a.ds->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          lds_store(&s_tag[rs], round);
-        }
-      }
-    }
-    if (lds_wait_eq(&s_tag[rs], round))
-      tile = s_tile[rs];
-    else
-      k9w_fault(a.ds, 0x20u, lane);
-    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile);
-    const bool valid = tile < ntiles;
-    PH(0); /* ticket */
-    uint32_t total = 0;
-    const uint32_t idx = tile * SUMA_TILE + (uint32_t)threadIdx.x; /* slot order = surfel order = stable order */
-    const bool has = valid && (tile * SUMA_TILE + (uint32_t)wave * 64u) < S;
-    if (has) {
-      const bool live = idx < S;
-      const Surfel4 in = load_surfel(sf, live ? idx : 0u); /* out-of-range lanes read surfel 0 (S > 0 here), masked below */
-      const K9Pre pre = k9_prepare(a, in);
-      PH(1); /* surfel loads + prepare issued */
-      const K9Rec rec = k9_gather(a, pre);
-      Surfel4 o;
-      int32_t mark_pix;
-      const bool keep = k9_finish(a, idx, in, pre, rec, o, &mark_pix) && live;
-      if (keep && mark_pix >= 0) a.integrated[mark_pix] = 1;
-      bool in_tile;
-      const bool emit = in_active_area(a, o, &in_tile) && keep;
-      s_ext[wave][buf][lane] = in_tile ? 1 : 0;
-      s_out[wave][buf][lane][0] = o.a;
-      s_out[wave][buf][lane][1] = o.b;
-      s_out[wave][buf][lane][2] = o.c;
-      s_out[wave][buf][lane][3] = o.d;
-      const unsigned long long eb = __ballot(emit);
-      kept_sum += __popcll(__ballot(keep));
-      total = __popcll(eb);
-      if (emit) s_slot[wave][buf][__popcll(eb & ((1ull << lane) - 1ull))] = (uint8_t)lane;
-      PH(2); /* pose entry + measurement gather + update arithmetic + LDS record */
-    }
-    if (valid) {
-      /* report (every wave of the block, also one whose 64 slots lie beyond S): the wave that reports last publishes
-       * the tile's total for the blocks behind */
-      uint32_t arrived = 0;
-      if (lane == 0) {
-        lds_store(&s_cnt[rs][wave], ((round + 1u) << 8) | total);
-        arrived = __hip_atomic_fetch_add(&s_arrived[rs], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-      arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
-      if (arrived == K9W_WAVES * ((round >> 2) + 1u) - 1u) {
-        uint32_t cnt = (lane < K9W_WAVES) ? (lds_load(&s_cnt[rs][lane]) & 0xffu) : 0u;
-        cnt = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(cnt), 63);
-        if (lane == 0) lookback_publish(a.status, a.group, tile, cnt, a.epoch);
-      }
-      PH(3); /* report + publish */
-    }
-    wave_lds_fence();
-    /* ---- the PREVIOUS round's records: offset and stream-out ---- */
-    if (prev_tile != 0xffffffffu) {
-      const uint32_t pr = round - 1u, ps = pr & (K9W_RING - 1u);
-      if (prev_has) {
-        /* surfels emitted by all earlier tiles: collected by the first wave that gets here, shared through LDS */
-        if (lds_load(&s_pref_tag[ps]) != pr) {
-          uint32_t before = pr + 1u;
-          if (lane == 0) before = __hip_atomic_fetch_max(&s_claim[ps], pr + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          before = (uint32_t)__builtin_amdgcn_readfirstlane((int)before);
-          if (before < pr + 1u) {
-            const uint32_t pre = lookback_collect<true>(a.status, a.group, prev_tile, a.epoch, lane, &a.ds->overflow);
-            if (lane == 0) {
-              s_pref[ps] = pre;
-              lds_store(&s_pref_tag[ps], pr);
-            }
-          } else if (!lds_wait_eq(&s_pref_tag[ps], pr)) {
-            k9w_fault(a.ds, 0x80u, lane);
-          }
-        }
-        wave_lds_fence();
-        uint32_t prefix = s_pref[ps];
-        /* + the counts of the lower waves of the tile (each lane < wave polls one word) */
-        {
-          uint32_t w = 0, spins = 0;
-          bool ok;
-          do {
-            if (lane < wave) w = lds_load(&s_cnt[ps][lane]);
-            ok = (lane >= wave) || ((w >> 8) == pr + 1u);
-            if (__ballot(!ok) == 0ull) break;
-            __builtin_amdgcn_s_sleep(1);
-          } while (++spins < SUMA_SPIN_LIMIT);
-          if (spins >= SUMA_SPIN_LIMIT) k9w_fault(a.ds, 0x100u, lane);
-          const uint32_t mine = (lane < wave) ? (w & 0xffu) : 0u;
-          prefix += (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(mine), 63);
-        }
-        PH(4); /* offset of the previous tile */
-        const uint32_t pb = buf ^ 1u;
-        for (uint32_t c = (uint32_t)lane; c < 4u * prev_total; c += 64u) {
-          const uint64_t d = 4ull * prefix + c;
-          if (d < 4ull * a.max_surfels) {
-            const uint32_t slot = s_slot[wave][pb][c >> 2];
-            store_stream(&dst4[d], s_out[wave][pb][slot][c & 3u]);
-            if (a.ex_flags != nullptr && (c & 3u) == 0) a.ex_flags[d >> 2] = s_ext[wave][pb][slot];
-          }
-        }
-        /* the last wave that holds surfels of the last tile knows where the updated map ends */
-        if (prev_tile == ntiles - 1u && lane == 0 && ((uint64_t)prev_tile * SUMA_TILE + ((uint32_t)wave + 1u) * 64u >= S)) {
-          const uint32_t tot = prefix + prev_total;
-          a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
-        }
-        PH(5); /* stream-out of the previous tile issued */
-      }
-      wave_lds_fence();
-      if (lane == 0) __hip_atomic_fetch_add(&s_finished[ps], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-      prev_tile = 0xffffffffu;
-    }
-    if (!valid) break;
-    prev_tile = tile;
-    prev_total = total;
-    prev_has = has;
-    if (has) buf ^= 1u;
-  }
-  PH_END(g_k9_phase);
-  /* ---- per-block and per-launch epilogue, without a barrier: the wave that arrives last does it ---- */
-  uint32_t last_wave = 0;
-  if (lane == 0) {
-    if (kept_sum) __hip_atomic_fetch_add(&s_keep, kept_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    last_wave = (__hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP) == K9W_WAVES - 1u) ? 1u : 0u;
-  }
-  last_wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)last_wave);
-  if (!last_wave) return;
-  uint32_t last_block = 0;
-  if (lane == 0) {
-    const uint32_t kc = lds_load(&s_keep);
-    if (kc) __hip_atomic_fetch_add(&a.ds->n_updated, kc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_block = (__hip_atomic_fetch_add(&a.ds->done_blocks, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u) ? 1u : 0u;
-  }
-  last_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)last_block);
-  if (!last_block) return;
-  /* every block has finished: nobody draws a ticket any more, and the next launch's accumulators (the other half)
-   * receive no straggling atomic of this launch */
-  for (uint32_t gi = (uint32_t)lane; gi < a.group_words; gi += 64u) a.group_next[gi] = 0;
-  if (lane == 0) {
-    a.ds->ticket = 0;
-    a.ds->done_blocks = 0;
-    if (ntiles == 0) a.ds->n_kept_updated = 0;
   }
 }
 
@@ -1136,16 +885,10 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   }
   {
     ProfScope ps(c, "k9_update_surfels", 128.0 * S + 16.0 * P);
-    static const bool block_form = getenv("SUMA_K9_BLOCK") != nullptr;
-    /* every launch that uses the 1024-tile look-back arrays takes the next epoch: the halves of the group
-     * accumulators alternate launch by launch, and each launch's finaliser clears the half of the next */
     a.epoch = ++c->epoch;
     a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
     a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
-    if (block_form)
-      k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), K9_THREADS, 0, st>>>(a);
-    else
-      k9_update_w<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), K9W_THREADS, 0, st>>>(a);
+    k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), K9_THREADS, 0, st>>>(a);
   }
   {
     ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);

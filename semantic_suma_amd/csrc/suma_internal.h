@@ -41,9 +41,8 @@ struct DevState {
   uint32_t ticket;         /* dynamic tile id of the look-back compaction kernels */
   uint32_t reserved0;      /* blocks-done counter of a self-closing objective pass (k_icp.hip) */
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
-  uint32_t done_blocks;    /* blocks of the wave-independent K9 that have finished (its last block re-arms the launch state) */
   uint32_t fault_site;     /* which bounded spin gave up (bit per site; reported with overflow bit 3) */
-  uint32_t pad[4];
+  uint32_t pad[5];
 };
 
 /* one cached submap tile in the device arena */

@@ -4,6 +4,6 @@
 SW="$1"; shift
 for i in 1 2 3; do
   for E in "" "$SW"; do
-    env $E python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$E]', 'steady', round(d['value'],1), 'cold', round(d.get('cold_start',{}).get('value',0),1))"
+    env $E python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 --no-host-vectors "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('[$E]', 'steady', round(d['value'],1), 'cold', round(d.get('cold_start',{}).get('value',0),1))"
   done
 done

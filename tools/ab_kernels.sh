@@ -3,8 +3,8 @@
 #   tools/ab_kernels.sh <libA> <libB>  -> gpurun_out/abk_A.json, abk_B.json + a side-by-side table
 A=$1; B=$2
 for i in 1 2; do
-  SUMA_HIP_LIB=$A python bench.py --cpu-scans 0 --adapter-scans 0 --profile-scans 40 --kernels-json gpurun_out/abk_A$i.json 2>/dev/null | tail -1 | cut -c1-80
-  SUMA_HIP_LIB=$B python bench.py --cpu-scans 0 --adapter-scans 0 --profile-scans 40 --kernels-json gpurun_out/abk_B$i.json 2>/dev/null | tail -1 | cut -c1-80
+  SUMA_HIP_LIB=$A python bench.py --cpu-scans 0 --adapter-scans 0 --no-host-vectors --profile-scans 40 --kernels-json gpurun_out/abk_A$i.json 2>/dev/null | tail -1 | cut -c1-80
+  SUMA_HIP_LIB=$B python bench.py --cpu-scans 0 --adapter-scans 0 --no-host-vectors --profile-scans 40 --kernels-json gpurun_out/abk_B$i.json 2>/dev/null | tail -1 | cut -c1-80
 done
 python - <<'PY'
 import json
