@@ -1,0 +1,447 @@
+"""oracle/glref.py -- TEST INFRASTRUCTURE: the reference's own GLSL executed by a real OpenGL implementation.
+
+Mesa's llvmpipe (swrast_dri.so, OpenGL 4.5 core) is driven without a window system through oracle/glref/gl_ctx.c; this
+module loads the shader sources of PRBonn/semantic_suma from /root/reference/src/shader (read where they lie, nothing is
+copied) and replays the GL calls the reference's host code makes around them (file:line cited per pass), so that the
+FIXED-FUNCTION half of the passes -- point and triangle rasterisation, the depth test on a DEPTH24_STENCIL8
+renderbuffer, transform-feedback order, rectangle-texture fetches -- is the behaviour of a conformant GL and not the
+builder's reading of the specification (oracle/ref_driver.cpp).  Used by tests/test_gl_reference.py and
+tests/golden/make_gl_golden.py only; the product never imports it.
+
+What a GL driver is free to choose (the last ulp of atan / asin / sin, fused multiply-adds, the precision of attribute
+interpolation) differs between llvmpipe, the vendor driver the reference was developed on, and include/suma_detmath.h;
+comparisons against this module therefore come in two kinds: EXACT where only fixed-function rules are involved (own
+pass-through shaders fed with the oracle's vertices), and STATISTICAL (fraction of texels that agree) where the
+reference's shaders compute the vertices themselves.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SHADER_DIR = os.environ.get("SUMA_REFERENCE_SHADERS", "/root/reference/src/shader")
+LIB = os.path.join(HERE, "_ref", "libsuma_glctx.so")
+
+# --- GL enums used below
+GL = dict(
+    VERSION=0x1F02, RENDERER=0x1F01, VERTEX_SHADER=0x8B31, GEOMETRY_SHADER=0x8DD9, FRAGMENT_SHADER=0x8B30,
+    COMPILE_STATUS=0x8B81, LINK_STATUS=0x8B82, INFO_LOG_LENGTH=0x8B84, ARRAY_BUFFER=0x8892, STATIC_DRAW=0x88E4,
+    DYNAMIC_COPY=0x88EA, FLOAT=0x1406, INT=0x1404, UNSIGNED_INT=0x1405, TEXTURE_RECTANGLE=0x84F5, TEXTURE_BUFFER=0x8C2A,
+    RGBA32F=0x8814, RGBA=0x1908, R32F=0x822E, RED=0x1903, TEXTURE0=0x84C0, TEXTURE_MIN_FILTER=0x2801,
+    TEXTURE_MAG_FILTER=0x2800, TEXTURE_WRAP_S=0x2802, TEXTURE_WRAP_T=0x2803, NEAREST=0x2600, LINEAR=0x2601,
+    CLAMP_TO_BORDER=0x812D, FRAMEBUFFER=0x8D40, RENDERBUFFER=0x8D41, COLOR_ATTACHMENT0=0x8CE0,
+    DEPTH_STENCIL_ATTACHMENT=0x821A, DEPTH24_STENCIL8=0x88F0, DEPTH_COMPONENT32F=0x8CAC, DEPTH_ATTACHMENT=0x8D00,
+    FRAMEBUFFER_COMPLETE=0x8CD5, COLOR_BUFFER_BIT=0x4000, DEPTH_BUFFER_BIT=0x100, DEPTH_TEST=0x0B71, LESS=0x0201,
+    LEQUAL=0x0203, POINTS=0x0000, TRIANGLE_STRIP=0x0005, TRANSFORM_FEEDBACK_BUFFER=0x8C8E, INTERLEAVED_ATTRIBS=0x8C8C,
+    TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN=0x8C88, QUERY_RESULT=0x8866, RASTERIZER_DISCARD=0x8C89, BLEND=0x0BE2,
+    ONE=1, FUNC_ADD=0x8006, SUBPIXEL_BITS=0x0D50, PROGRAM_POINT_SIZE=0x8642, DEPTH_BITS=0x0D56,
+)
+
+
+class GLError(RuntimeError):
+    pass
+
+
+class Context:
+    """process-wide GL context + ctypes access to the entry points"""
+    _inst = None
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def __init__(self):
+        if not os.path.exists(LIB):
+            build_shim()
+        self.L = C.CDLL(LIB)
+        self.L.gl_ctx_create.argtypes = [C.c_char_p]
+        self.L.gl_ctx_error.restype = C.c_char_p
+        self.L.gl_ctx_proc.restype = C.c_void_p
+        self.L.gl_ctx_proc.argtypes = [C.c_char_p]
+        rc = self.L.gl_ctx_create(os.environ.get("SUMA_SWRAST_DRI", "").encode())
+        if rc != 0:
+            raise GLError(f"no software GL context ({rc}): {self.L.gl_ctx_error().decode()}")
+        self._fn = {}
+        gs = self.fn("glGetString", C.c_char_p, C.c_uint)
+        self.version = gs(GL["VERSION"]).decode()
+        self.renderer = gs(GL["RENDERER"]).decode()
+
+    def fn(self, name, restype, *argtypes):
+        key = (name, restype, argtypes)
+        f = self._fn.get(key)
+        if f is None:
+            p = self.L.gl_ctx_proc(name.encode())
+            if not p:
+                raise GLError(f"GL entry point {name} not found")
+            f = C.CFUNCTYPE(restype, *argtypes)(p)
+            self._fn[key] = f
+        return f
+
+    def check(self, what=""):
+        e = self.fn("glGetError", C.c_uint)()
+        if e:
+            raise GLError(f"GL error 0x{e:x} after {what}")
+
+
+def build_shim():
+    """compile oracle/glref/gl_ctx.c -> oracle/_ref/libsuma_glctx.so (needs the Mesa DRI headers of this image)"""
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    subprocess.check_call(["gcc", "-O1", "-fPIC", "-shared", "-o", LIB, os.path.join(HERE, "glref", "gl_ctx.c"), "-ldl"])
+
+
+def available():
+    try:
+        Context.get()
+        return True
+    except (GLError, OSError, subprocess.CalledProcessError):
+        return False
+
+
+def shader_source(name):
+    """a shader of the reference with its #include lines resolved (glow does that at load time)"""
+    import re
+    with open(os.path.join(SHADER_DIR, name)) as f:
+        src = f.read()
+
+    def inc(m):
+        with open(os.path.join(os.path.dirname(SHADER_DIR), m.group(1))) as g:
+            return g.read()
+    return re.sub(r'#include\s+"([^"]+)"', inc, src)
+
+
+u32, i32, f32, vp = C.c_uint, C.c_int, C.c_float, C.c_void_p
+
+
+class Program:
+    def __init__(self, stages, tf_varyings=None, from_reference=True):
+        """stages: {GL stage enum name: file name under src/shader (from_reference) or GLSL text}"""
+        g = Context.get()
+        self.g = g
+        self.id = g.fn("glCreateProgram", u32)()
+        for kind, src in stages.items():
+            text = shader_source(src) if from_reference else src
+            sh = g.fn("glCreateShader", u32, u32)(GL[kind])
+            buf = C.c_char_p(text.encode())
+            g.fn("glShaderSource", None, u32, i32, C.POINTER(C.c_char_p), vp)(sh, 1, C.byref(buf), None)
+            g.fn("glCompileShader", None, u32)(sh)
+            ok = i32(0)
+            g.fn("glGetShaderiv", None, u32, u32, C.POINTER(i32))(sh, GL["COMPILE_STATUS"], C.byref(ok))
+            if not ok.value:
+                log = C.create_string_buffer(8192)
+                g.fn("glGetShaderInfoLog", None, u32, i32, vp, vp)(sh, 8192, None, log)
+                raise GLError(f"compile {src if from_reference else kind}: {log.value.decode()}")
+            g.fn("glAttachShader", None, u32, u32)(self.id, sh)
+        if tf_varyings:
+            arr = (C.c_char_p * len(tf_varyings))(*[v.encode() for v in tf_varyings])
+            g.fn("glTransformFeedbackVaryings", None, u32, i32, vp, u32)(self.id, len(tf_varyings), arr, GL["INTERLEAVED_ATTRIBS"])
+        g.fn("glLinkProgram", None, u32)(self.id)
+        ok = i32(0)
+        g.fn("glGetProgramiv", None, u32, u32, C.POINTER(i32))(self.id, GL["LINK_STATUS"], C.byref(ok))
+        if not ok.value:
+            log = C.create_string_buffer(8192)
+            g.fn("glGetProgramInfoLog", None, u32, i32, vp, vp)(self.id, 8192, None, log)
+            raise GLError(f"link: {log.value.decode()}")
+
+    def use(self):
+        self.g.fn("glUseProgram", None, u32)(self.id)
+
+    def loc(self, name):
+        return self.g.fn("glGetUniformLocation", i32, u32, C.c_char_p)(self.id, name.encode())
+
+    def set(self, **uniforms):
+        """ints / bools -> glUniform1i, floats -> glUniform1f, 4x4 numpy (row-major) -> glUniformMatrix4fv (transposed),
+        length-2/3/4 float sequences -> glUniformNf"""
+        self.use()
+        g = self.g
+        for name, v in uniforms.items():
+            l = self.loc(name)
+            if l < 0:
+                continue  # optimised out / not declared in this program: glow ignores it too
+            if isinstance(v, (bool, np.bool_)) or isinstance(v, (int, np.integer)):
+                g.fn("glUniform1i", None, i32, i32)(l, int(v))
+            elif isinstance(v, (float, np.floating)):
+                g.fn("glUniform1f", None, i32, f32)(l, float(v))
+            else:
+                a = np.asarray(v, dtype=np.float32)
+                if a.shape == (4, 4):
+                    m = np.ascontiguousarray(a.T)  # column-major, as Eigen hands it over
+                    g.fn("glUniformMatrix4fv", None, i32, i32, C.c_ubyte, vp)(l, 1, 0, m.ctypes.data)
+                elif a.size == 2:
+                    g.fn("glUniform2f", None, i32, f32, f32)(l, *map(float, a))
+                elif a.size == 3:
+                    g.fn("glUniform3f", None, i32, f32, f32, f32)(l, *map(float, a))
+                elif a.size == 4:
+                    g.fn("glUniform4f", None, i32, f32, f32, f32, f32)(l, *map(float, a))
+                else:
+                    raise ValueError(name)
+
+
+def gen(kind):
+    g = Context.get()
+    out = u32(0)
+    g.fn("glGen" + kind, None, i32, C.POINTER(u32))(1, C.byref(out))
+    return out.value
+
+
+class Buffer:
+    def __init__(self, data=None, nbytes=0, target="ARRAY_BUFFER"):
+        g = Context.get()
+        self.g, self.id, self.target = g, gen("Buffers"), GL[target]
+        if data is not None:
+            data = np.ascontiguousarray(data)
+            nbytes = data.nbytes
+        self.nbytes = nbytes
+        g.fn("glBindBuffer", None, u32, u32)(self.target, self.id)
+        g.fn("glBufferData", None, u32, C.c_ssize_t, vp, u32)(self.target, nbytes, data.ctypes.data if data is not None else None,
+                                                                GL["DYNAMIC_COPY"])
+
+    def read(self, dtype, count):
+        out = np.empty(count, dtype=dtype)
+        g = self.g
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], self.id)
+        g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["ARRAY_BUFFER"], 0, out.nbytes, out.ctypes.data)
+        return out
+
+
+class RectTexture:
+    """GL_TEXTURE_RECTANGLE, RGBA32F (glow::GlTextureRectangle of Frame.h:63-70); row 0 = bottom row"""
+
+    def __init__(self, w, h, data=None, filter="NEAREST"):
+        g = Context.get()
+        self.g, self.w, self.h, self.id = g, w, h, gen("Textures")
+        T = GL["TEXTURE_RECTANGLE"]
+        g.fn("glBindTexture", None, u32, u32)(T, self.id)
+        if data is not None:
+            data = np.ascontiguousarray(data, dtype=np.float32).reshape(h, w, 4)
+        g.fn("glTexImage2D", None, u32, i32, i32, i32, i32, i32, u32, u32, vp)(
+            T, 0, GL["RGBA32F"], w, h, 0, GL["RGBA"], GL["FLOAT"], data.ctypes.data if data is not None else None)
+        for pname, val in (("TEXTURE_MIN_FILTER", filter), ("TEXTURE_MAG_FILTER", filter), ("TEXTURE_WRAP_S", "CLAMP_TO_BORDER"),
+                           ("TEXTURE_WRAP_T", "CLAMP_TO_BORDER")):
+            g.fn("glTexParameteri", None, u32, u32, i32)(T, GL[pname], GL[val])
+
+    def bind(self, unit):
+        self.g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + unit)
+        self.g.fn("glBindTexture", None, u32, u32)(GL["TEXTURE_RECTANGLE"], self.id)
+
+    def read(self):
+        out = np.empty((self.h, self.w, 4), dtype=np.float32)
+        g = self.g
+        g.fn("glBindTexture", None, u32, u32)(GL["TEXTURE_RECTANGLE"], self.id)
+        g.fn("glGetTexImage", None, u32, i32, u32, u32, vp)(GL["TEXTURE_RECTANGLE"], 0, GL["RGBA"], GL["FLOAT"], out.ctypes.data)
+        return out
+
+
+class BufferTexture:
+    """samplerBuffer over a float4 array (glow::GlTextureBuffer poseTexture_, SurfelMap.cpp:25)"""
+
+    def __init__(self, data):
+        g = Context.get()
+        self.g = g
+        self.buf = Buffer(np.ascontiguousarray(data, dtype=np.float32), target="ARRAY_BUFFER")
+        self.id = gen("Textures")
+        g.fn("glBindTexture", None, u32, u32)(GL["TEXTURE_BUFFER"], self.id)
+        g.fn("glTexBuffer", None, u32, u32, u32)(GL["TEXTURE_BUFFER"], GL["RGBA32F"], self.buf.id)
+
+    def bind(self, unit):
+        self.g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + unit)
+        self.g.fn("glBindTexture", None, u32, u32)(GL["TEXTURE_BUFFER"], self.id)
+
+
+class Framebuffer:
+    """glow::GlFramebuffer with a DEPTH24_STENCIL8 renderbuffer (SurfelMap.cpp:103-122, 172-173; Preprocessing.cpp:22-28)"""
+
+    def __init__(self, w, h, depth="DEPTH24_STENCIL8"):
+        g = Context.get()
+        self.g, self.w, self.h = g, w, h
+        self.id = gen("Framebuffers")
+        self.rbo = gen("Renderbuffers")
+        g.fn("glBindRenderbuffer", None, u32, u32)(GL["RENDERBUFFER"], self.rbo)
+        g.fn("glRenderbufferStorage", None, u32, u32, i32, i32)(GL["RENDERBUFFER"], GL[depth], w, h)
+        self.bind()
+        att = "DEPTH_STENCIL_ATTACHMENT" if depth == "DEPTH24_STENCIL8" else "DEPTH_ATTACHMENT"
+        g.fn("glFramebufferRenderbuffer", None, u32, u32, u32, u32)(GL["FRAMEBUFFER"], GL[att], GL["RENDERBUFFER"], self.rbo)
+
+    def bind(self):
+        self.g.fn("glBindFramebuffer", None, u32, u32)(GL["FRAMEBUFFER"], self.id)
+
+    def attach(self, textures):
+        g = self.g
+        self.bind()
+        for k, t in enumerate(textures):
+            g.fn("glFramebufferTexture2D", None, u32, u32, u32, u32, i32)(GL["FRAMEBUFFER"], GL["COLOR_ATTACHMENT0"] + k,
+                                                                          GL["TEXTURE_RECTANGLE"], t.id, 0)
+        bufs = (u32 * len(textures))(*[GL["COLOR_ATTACHMENT0"] + k for k in range(len(textures))])
+        g.fn("glDrawBuffers", None, i32, vp)(len(textures), bufs)
+        st = g.fn("glCheckFramebufferStatus", u32, u32)(GL["FRAMEBUFFER"])
+        if st != GL["FRAMEBUFFER_COMPLETE"]:
+            raise GLError(f"framebuffer incomplete: 0x{st:x}")
+
+
+SURFEL_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("z", "<f4"), ("radius", "<f4"), ("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4"),
+                         ("confidence", "<f4"), ("timestamp", "<i4"), ("color", "<f4"), ("weight", "<f4"), ("count", "<f4"),
+                         ("r", "<f4"), ("g", "<f4"), ("b", "<f4"), ("w", "<f4")])
+
+
+def surfel_vao(buf):
+    """vao_surfels_, SurfelMap.cpp:46-55: the 64-byte Surfel record as five vertex attributes"""
+    g = Context.get()
+    vao = gen("VertexArrays")
+    g.fn("glBindVertexArray", None, u32)(vao)
+    g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], buf.id)
+    vap = g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)
+    vaip = g.fn("glVertexAttribIPointer", None, u32, i32, u32, i32, vp)
+    en = g.fn("glEnableVertexAttribArray", None, u32)
+    vap(0, 4, GL["FLOAT"], 0, 64, 0)
+    vap(1, 4, GL["FLOAT"], 0, 64, 16)
+    vaip(2, 1, GL["INT"], 64, 32)
+    vap(3, 3, GL["FLOAT"], 0, 64, 36)
+    vap(4, 4, GL["FLOAT"], 0, 64, 48)
+    for k in range(5):
+        en(k)
+    return vao
+
+
+def common_state(w, h, depth_func="LESS"):
+    g = Context.get()
+    g.fn("glEnable", None, u32)(GL["DEPTH_TEST"])
+    g.fn("glDepthFunc", None, u32)(GL[depth_func])
+    g.fn("glClearColor", None, f32, f32, f32, f32)(0, 0, 0, 0)
+    g.fn("glViewport", None, i32, i32, i32, i32)(0, 0, w, h)
+
+
+def clear():
+    Context.get().fn("glClear", None, u32)(GL["COLOR_BUFFER_BIT"] | GL["DEPTH_BUFFER_BIT"])
+
+
+def draw_points(vao, n):
+    g = Context.get()
+    g.fn("glBindVertexArray", None, u32)(vao)
+    g.fn("glDrawArrays", None, u32, i32, i32)(GL["POINTS"], 0, n)
+
+
+# =====================================================================================================================
+# passes
+# =====================================================================================================================
+class SurfelRenderer:
+    """SurfelMap::render / render_active / render_inactive with the reference's render_surfels.{vert,geom,frag}
+    (SurfelMap.cpp:172-186 program + framebuffer, :847-1021 render(), :1023-1114 the single passes)"""
+
+    def __init__(self, params):
+        self.p = params
+        self.W, self.H = params.model_width, params.model_height
+        self.prog = Program({"VERTEX_SHADER": "render_surfels.vert", "GEOMETRY_SHADER": "render_surfels.geom",
+                             "FRAGMENT_SHADER": "render_surfels.frag"})
+        # SurfelMap.cpp:179-186: the uniforms of the render program
+        self.prog.set(fov_up=float(params.model_fov_up), fov_down=float(params.model_fov_down),
+                      max_depth=float(params.model_max_depth), min_depth=float(params.model_min_depth),
+                      use_stability=bool(params.use_stability), poseBuffer=5)
+        self.fbo = Framebuffer(self.W, self.H)
+
+    def render_pass(self, surfels, poses, pose, conf_threshold, timestamp_threshold, render_old, depth_func="LESS",
+                    targets=None, clear_first=True):
+        """one glDrawArrays(GL_POINTS, 0, surfels_.size()) of render(): returns the three attachments as (H, W, 4)"""
+        W, H = self.W, self.H
+        surfels = np.ascontiguousarray(surfels)
+        vbo = Buffer(surfels.view(np.uint8))
+        vao = surfel_vao(vbo)
+        ptex = BufferTexture(np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 4))
+        if targets is None:
+            targets = [RectTexture(W, H) for _ in range(3)]
+        common_state(W, H, depth_func)
+        ptex.bind(5)
+        self.fbo.attach(targets)
+        inv_pose = np.linalg.inv(np.asarray(pose, dtype=np.float32).astype(np.float32))  # Eigen: Matrix4f::inverse()
+        self.prog.set(conf_threshold=float(conf_threshold), timestamp_threshold=int(timestamp_threshold),
+                      inv_pose=inv_pose.astype(np.float32), render_old_surfels=bool(render_old))
+        self.prog.use()
+        if clear_first:
+            clear()
+        draw_points(vao, surfels.shape[0])
+        Context.get().fn("glFinish", None)()
+        Context.get().check("render_surfels draw")
+        return targets
+
+    def render(self, surfels, poses, pose, conf_threshold, timestamp_threshold, render_old):
+        return [t.read() for t in self.render_pass(surfels, poses, pose, conf_threshold, timestamp_threshold, render_old)]
+
+
+PASS_VS = """#version 330 core
+layout (location = 0) in vec4 pos;      // clip-space position, w = 1
+layout (location = 1) in vec2 tc;
+layout (location = 2) in float prim;    // primitive id + 1 (float: exact up to 2^24)
+out vec2 texCoords;
+flat out float id;
+void main() { gl_Position = pos; texCoords = tc; id = prim; }
+"""
+PASS_FS = """#version 330 core
+in vec2 texCoords;
+flat in float id;
+uniform bool disc;
+layout (location = 0) out vec4 o;
+void main() {
+  if (disc && dot(texCoords, texCoords) > 1.0f) discard;
+  o = vec4(id, gl_FragCoord.z, texCoords);
+}
+"""
+
+
+class QuadRaster:
+    """Fixed-function check: the oracle's OWN quad corners (ora_debug_render_quads) go through GL's clipping,
+    rasterisation and depth test behind a pass-through vertex shader -- nothing but the rules of the GL pipeline
+    decides which primitive owns a pixel.  strips: [n, 4, 3] corners in [0, 1]^3 (x may leave [0, 1] at the seam)."""
+
+    def __init__(self, W, H, depth="DEPTH24_STENCIL8"):
+        self.W, self.H = W, H
+        self.prog = Program({"VERTEX_SHADER": PASS_VS, "FRAGMENT_SHADER": PASS_FS}, from_reference=False)
+        self.fbo = Framebuffer(W, H, depth)
+
+    def run(self, corners, ids, disc=True, depth_func="LESS", flat_z=False, depth_test=True):
+        g = Context.get()
+        corners = np.asarray(corners, dtype=np.float32)
+        n = corners.shape[0]
+        tcs = np.array([[-1, -1], [1, -1], [-1, 1], [1, 1]], dtype=np.float32)
+        v = np.zeros((n, 4, 7), dtype=np.float32)
+        # gl_Position = vec4(2.0 * project2model(...) - 1.0, 1.0f), render_surfels.geom:104-117 -- in fp32, as the shader does
+        v[:, :, 0:3] = np.float32(2.0) * corners - np.float32(1.0)
+        if flat_z:
+            v[:, :, 2] = v[:, :1, 2]
+        v[:, :, 3] = 1.0
+        v[:, :, 4:6] = tcs[None]
+        v[:, :, 6] = (np.asarray(ids, dtype=np.float32) + 1.0)[:, None]
+        vbo = Buffer(v.reshape(-1, 7))
+        vao = gen("VertexArrays")
+        g.fn("glBindVertexArray", None, u32)(vao)
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], vbo.id)
+        vap = g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)
+        en = g.fn("glEnableVertexAttribArray", None, u32)
+        vap(0, 4, GL["FLOAT"], 0, 28, 0)
+        vap(1, 2, GL["FLOAT"], 0, 28, 16)
+        vap(2, 1, GL["FLOAT"], 0, 28, 24)
+        for k in range(3):
+            en(k)
+        tex = RectTexture(self.W, self.H)
+        common_state(self.W, self.H, depth_func)
+        if not depth_test:
+            g.fn("glDisable", None, u32)(GL["DEPTH_TEST"])
+        self.fbo.attach([tex])
+        self.prog.set(disc=bool(disc))
+        self.prog.use()
+        clear()
+        first = (i32 * n)(*range(0, 4 * n, 4))
+        count = (i32 * n)(*([4] * n))
+        g.fn("glMultiDrawArrays", None, u32, vp, vp, i32)(GL["TRIANGLE_STRIP"], first, count, n)
+        g.fn("glFinish", None)()
+        g.check("pass-through quads")
+        out = tex.read()
+        return out[..., 0].astype(np.int64) - 1, out[..., 1]  # winner id per pixel (-1: none), window-space depth
+
+
+def limits():
+    g = Context.get()
+    v = i32(0)
+    g.fn("glGetIntegerv", None, u32, C.POINTER(i32))(GL["SUBPIXEL_BITS"], C.byref(v))
+    return {"version": g.version, "renderer": g.renderer, "subpixel_bits": v.value}

@@ -302,7 +302,9 @@ static void o_render_pass(const ora_ctx* c, const float* inv_pose, float conf_th
       if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(pr[k].z)) bad = 1;
       vt[k].X = (int64_t)sdm_floor(xw * 256.0f + 0.5f);
       vt[k].Y = (int64_t)sdm_floor(yw * 256.0f + 0.5f);
-      vt[k].z = pr[k].z;
+      /* gl_Position.z = 2 z01 - 1 (render_surfels.geom:104-117), viewport with depth range [0, 1]: z_w = 0.5 z_ndc + 0.5
+       * -- in fp32 this is z01 again for only 84 % of the values (a real GL interpolates and quantises z_w) */
+      vt[k].z = 0.5f * (2.0f * pr[k].z - 1.0f) + 0.5f;
       vt[k].tu = tcu[k];
       vt[k].tv = tcv[k];
     }
@@ -342,6 +344,44 @@ static inline uint32_t o_key_id(uint64_t key, int tie) {
   uint32_t low = (uint32_t)(key & 0xffffffffu);
   return tie == O_TIE_LOW_INDEX ? low : (0xffffffffu - low);
 }
+
+/* the rasteriser alone, for tests/test_gl_reference.py: the quads are given (n x 4 corners in [0,1]^3, drawn in this
+ * order as the strip (v0,v1,v2), (v2,v1,v3) with primitive id ids[k]), a real GL implementation rasterises the same
+ * vertices behind a pass-through shader, and the two winner maps are compared.  use_disc = 0: no fragment is
+ * discarded; use_depth = 0: no depth test, the last primitive that covers a pixel owns it (ids ascending).
+ * winner: W x H, primitive id or -1. */
+void ora_debug_raster_quads(int32_t W, int32_t H, const float* corners, const uint32_t* ids, uint32_t n, int use_disc,
+                            int use_depth, int64_t* winner) {
+  uint64_t* zbuf = (uint64_t*)malloc((size_t)W * (size_t)H * sizeof(uint64_t));
+  for (size_t k = 0; k < (size_t)W * (size_t)H; ++k) zbuf[k] = ~0ull;
+  static const float tcu[4] = {-1.f, 1.f, -1.f, 1.f}, tcv[4] = {-1.f, -1.f, 1.f, 1.f};
+  const int tie = use_depth ? O_TIE_LOW_INDEX : O_TIE_HIGH_INDEX_NEW;
+  for (uint32_t q = 0; q < n; ++q) {
+    o_rvtx vt[4];
+    int bad = 0;
+    for (int k = 0; k < 4; ++k) {
+      const float* c = corners + 12 * (size_t)q + 3 * k;
+      const float xw = c[0] * (float)W, yw = c[1] * (float)H;
+      if (sdm_isnan(xw) || sdm_isnan(yw) || sdm_isnan(c[2])) bad = 1;
+      vt[k].X = (int64_t)sdm_floor(xw * 256.0f + 0.5f);
+      vt[k].Y = (int64_t)sdm_floor(yw * 256.0f + 0.5f);
+      vt[k].z = use_depth ? 0.5f * (2.0f * c[2] - 1.0f) + 0.5f : 0.0f;
+      vt[k].tu = use_disc ? tcu[k] : 0.0f;
+      vt[k].tv = use_disc ? tcv[k] : 0.0f;
+    }
+    if (bad) continue;
+    o_raster_tri(vt[0], vt[1], vt[2], W, H, zbuf, ids[q], tie);
+    o_raster_tri(vt[2], vt[1], vt[3], W, H, zbuf, ids[q], tie);
+  }
+  for (size_t k = 0; k < (size_t)W * (size_t)H; ++k)
+    winner[k] = (zbuf[k] == ~0ull) ? -1 : (int64_t)o_key_id(zbuf[k], tie);
+  free(zbuf);
+}
+/* o_depth24 of n window depths */
+void ora_debug_depth24(const float* zw, uint32_t n, uint32_t* out) {
+  for (uint32_t k = 0; k < n; ++k) out[k] = o_depth24(zw[k]);
+}
+
 
 /* write vertex / normal / semantic of the winning surfel (render_surfels.frag:30-32) */
 static void o_render_resolve(const ora_ctx* c, const float* inv_pose_a, const float* inv_pose_b, const uint64_t* zbuf,

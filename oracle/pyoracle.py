@@ -112,6 +112,8 @@ def lib(variant: str = ""):
     L.ora_map_last_extraction.restype = C.c_uint32
     L.ora_map_last_extraction.argtypes = [vp, vp]
     L.ora_debug_render_quads.argtypes = [vp, vp, C.c_float, C.c_int, C.c_int32, vp, vp, vp]
+    L.ora_debug_raster_quads.argtypes = [C.c_int32, C.c_int32, vp, vp, C.c_uint32, C.c_int, C.c_int, vp]
+    L.ora_debug_depth24.argtypes = [vp, C.c_uint32, vp]
     L.ora_pipeline_create.restype = vp
     L.ora_pipeline_create.argtypes = [C.POINTER(SumaParams)]
     L.ora_pipeline_destroy.argtypes = [vp]
@@ -357,6 +359,20 @@ class Oracle:
         pn = np.zeros((max(n, 1), 6), dtype=np.float32)
         self.L.ora_debug_render_quads(self.h, _ptr(po), conf_threshold, mode, thr, _ptr(emitted), _ptr(corners), _ptr(pn))
         return emitted[:n], corners[:n], pn[:n]
+
+    def debug_raster_quads(self, W, H, corners, ids, use_disc=True, use_depth=True):
+        """the triangle rasteriser alone on given quads ([n, 4, 3] corners in [0,1]^3): winner id per pixel, -1 = none"""
+        corners = np.ascontiguousarray(corners, dtype=np.float32)
+        ids = np.ascontiguousarray(ids, dtype=np.uint32)
+        win = np.zeros((H, W), dtype=np.int64)
+        self.L.ora_debug_raster_quads(W, H, _ptr(corners), _ptr(ids), ids.shape[0], int(use_disc), int(use_depth), _ptr(win))
+        return win
+
+    def debug_depth24(self, zw):
+        zw = np.ascontiguousarray(zw, dtype=np.float32)
+        out = np.zeros(zw.shape[0], dtype=np.uint32)
+        self.L.ora_debug_depth24(_ptr(zw), zw.shape[0], _ptr(out))
+        return out
 
     def map_submap_origin(self):
         ij = np.zeros(2, dtype=np.int32)

@@ -179,5 +179,22 @@ def main():
     return 0
 
 
+def build_gl_shim():
+    """oracle/_ref/libsuma_glctx.so: the window-system-free GL context of oracle/glref.py (Mesa DRI headers needed;
+    without them the GL-backed tests skip)"""
+    src = os.path.join(HERE, "glref", "gl_ctx.c")
+    lib = os.path.join(OUT, "libsuma_glctx.so")
+    if not os.path.exists("/usr/include/GL/internal/dri_interface.h"):
+        return
+    if os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(src):
+        return
+    os.makedirs(OUT, exist_ok=True)
+    cmd = [os.environ.get("CC", "gcc"), "-O1", "-fPIC", "-shared", "-o", lib, src, "-ldl"]
+    print(" ".join(cmd))
+    subprocess.check_call(cmd)
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    rc = main()
+    build_gl_shim()
+    sys.exit(rc)

@@ -114,7 +114,7 @@ static bool rasterize_point(const vec4& clip, int W, int H, raster_point* out) {
   if (px < 0 || py < 0 || px >= W || py >= H) return false; /* on the far clip edge: no pixel centre covered */
   out->px = px;
   out->py = py;
-  out->z24 = (uint32_t)(zw * 16777215.0f + 0.5f); /* GL_DEPTH24_STENCIL8: unorm24, round to nearest */
+  out->z24 = (uint32_t)__builtin_rintf(zw * 16777215.0f); /* GL_DEPTH24_STENCIL8: unorm24, nearest-even of the fp32 product (pinned against llvmpipe, oracle/glref.py) */
   return true;
 }
 

@@ -86,6 +86,10 @@ uint32_t ora_map_last_extraction(const ora_ctx* c, int32_t* ij); /* returns the 
 /* K4 vertex + geometry stage per surfel, before rasterisation (tests/test_ref_shaders.py) */
 void ora_debug_render_quads(const ora_ctx* c, const float pose[16], float conf_threshold, int mode, int32_t thr,
                             uint8_t* emitted, float* corners, float* pn);
+/* the triangle rasteriser / the depth quantisation alone (tests/test_gl_reference.py compares them with a real GL) */
+void ora_debug_raster_quads(int32_t W, int32_t H, const float* corners, const uint32_t* ids, uint32_t n, int use_disc,
+                            int use_depth, int64_t* winner);
+void ora_debug_depth24(const float* zw, uint32_t n, uint32_t* out);
 void ora_map_submap_origin(const ora_ctx* c, int32_t* ij);
 
 /* results of the two device-side parts of SurfelMapping::checkLoopClosure (field for field the product's

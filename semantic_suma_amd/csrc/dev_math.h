@@ -98,7 +98,9 @@ SDEV bool is_dynamic_label(float l) {
 }
 
 /* 24-bit unorm depth (GL_DEPTH24_STENCIL8 renderbuffers of the reference) */
-SDEV uint32_t depth24(float zw) { return (uint32_t)(zw * 16777215.0f + 0.5f); }
+/* nearest-even of the fp32 product (v_rndne_f32): the rule of a real GL implementation (Mesa llvmpipe, pinned in
+ * round 4: DESIGN.md section 2); rounds 1-3 used (uint32_t)(zw * 16777215.0f + 0.5f), whose fp32 add rounds twice */
+SDEV uint32_t depth24(float zw) { return (uint32_t)__builtin_rintf(zw * 16777215.0f); }
 
 /* spherical projection parameters of one image (data or model) */
 struct proj_t {

@@ -315,7 +315,9 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
           const float depth = len3(corner[k]);
           const float pitch = -sdm_asin(corner[k].z / depth);
           const float y01 = 1.0f - ((pitch * SUMA_RAD2DEG_F) + a.q.fov_up) / a.q.fov;
-          Z[k] = (depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth);
+          /* window depth as shader (gl_Position.z = 2 z01 - 1, render_surfels.geom:104-117) and viewport (z_w = 0.5 z_ndc +
+           * 0.5) form it: in fp32 that is z01 again for only 84 % of the values */
+          Z[k] = 0.5f * (2.0f * ((depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth)) - 1.0f) + 0.5f;
           const float yw = y01 * a.q.height;
           if (sdm_isnan(yw) || sdm_isnan(Z[k])) bad = true;
           Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);

@@ -21,12 +21,19 @@
 #include "../../include/suma_hip_dist.h"
 
 #define SUMA_DIST_MAX_DOUBLES 64u
+/* the exchange of suma_run_hypotheses moves an n_hyp x 18 table (n_hyp <= 64): one collective per scan */
+#define SUMA_DIST_TABLE_DOUBLES (64u * 18u)
 
 struct suma_dist_comm {
   ncclComm_t comm;
   int world, rank;
   double *d_send, *d_recv; /* device staging */
   double* h_buf;           /* pinned: send block followed by world receive blocks */
+  /* all-reduce of the hypothesis table: a stream of the communicator's own, on the communicator's device (round-3
+   * advisor: a thread_local stream was created on whatever device was current and never destroyed) */
+  int device;
+  hipStream_t ar_stream;
+  double *d_table, *h_table; /* SUMA_DIST_TABLE_DOUBLES each (pinned host) */
   std::string err;
 };
 
@@ -56,6 +63,10 @@ extern "C" int suma_dist_comm_create(const char id[SUMA_DIST_ID_BYTES], int worl
   c->world = world;
   c->rank = rank;
   c->d_send = c->d_recv = c->h_buf = nullptr;
+  c->ar_stream = nullptr;
+  c->d_table = c->h_table = nullptr;
+  c->device = 0;
+  (void)hipGetDevice(&c->device); /* the device the communicator is created on (the calling thread's current device) */
   ncclUniqueId u;
   memcpy(&u, id, sizeof(u));
   (void)hipGetLastError(); /* RCCL reports a stale, already handled HIP error of the calling thread as its own */
@@ -67,7 +78,10 @@ extern "C" int suma_dist_comm_create(const char id[SUMA_DIST_ID_BYTES], int worl
   }
   const size_t blk = SUMA_DIST_MAX_DOUBLES * sizeof(double);
   if (hipMalloc((void**)&c->d_send, blk) != hipSuccess || hipMalloc((void**)&c->d_recv, blk * (size_t)world) != hipSuccess ||
-      hipHostMalloc((void**)&c->h_buf, blk * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess) {
+      hipHostMalloc((void**)&c->h_buf, blk * (size_t)(world + 1), hipHostMallocDefault) != hipSuccess ||
+      hipMalloc((void**)&c->d_table, SUMA_DIST_TABLE_DOUBLES * sizeof(double)) != hipSuccess ||
+      hipHostMalloc((void**)&c->h_table, SUMA_DIST_TABLE_DOUBLES * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+      hipStreamCreateWithFlags(&c->ar_stream, hipStreamNonBlocking) != hipSuccess) {
     g_dist_error = "suma_dist_comm_create: staging allocation failed";
     suma_dist_comm_destroy(c);
     return SUMA_ERR_HIP;
@@ -81,6 +95,12 @@ extern "C" void suma_dist_comm_destroy(suma_dist_comm* c) {
   if (c->d_send) hipFree(c->d_send);
   if (c->d_recv) hipFree(c->d_recv);
   if (c->h_buf) hipHostFree(c->h_buf);
+  if (c->d_table) hipFree(c->d_table);
+  if (c->h_table) hipHostFree(c->h_table);
+  if (c->ar_stream) {
+    hipStreamSynchronize(c->ar_stream);
+    hipStreamDestroy(c->ar_stream);
+  }
   if (c->comm) ncclCommDestroy(c->comm);
   delete c;
 }
@@ -121,30 +141,31 @@ extern "C" int suma_gather_poses(suma_ctx* ctx, suma_dist_comm* c, const double 
  * ncclAllReduce on a stream of its own -- the runner's pipeline is internal to it -- in chunks of the staging block. */
 extern "C" int suma_dist_allreduce_sum(suma_dist_comm* c, const double* send, uint32_t count, double* out) {
   if (!c || !send || !out || count == 0) return SUMA_ERR_INVALID;
-  static thread_local hipStream_t stream = nullptr;
-  if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) {
-    c->err = "suma_dist_allreduce_sum: hipStreamCreate failed";
+  int cur = -1;
+  if (hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) != hipSuccess) {
+    c->err = "suma_dist_allreduce_sum: cannot make the communicator's device current";
     return SUMA_ERR_HIP;
   }
-  for (uint32_t lo = 0; lo < count; lo += SUMA_DIST_MAX_DOUBLES) {
-    const uint32_t n = count - lo < SUMA_DIST_MAX_DOUBLES ? count - lo : SUMA_DIST_MAX_DOUBLES;
-    memcpy(c->h_buf, send + lo, n * sizeof(double));
-    if (hipMemcpyAsync(c->d_send, c->h_buf, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) {
+  hipStream_t stream = c->ar_stream;
+  /* in place on the device, one collective per SUMA_DIST_TABLE_DOUBLES: the whole n_hyp x 18 table of a scan in one */
+  for (uint32_t lo = 0; lo < count; lo += SUMA_DIST_TABLE_DOUBLES) {
+    const uint32_t n = count - lo < SUMA_DIST_TABLE_DOUBLES ? count - lo : SUMA_DIST_TABLE_DOUBLES;
+    memcpy(c->h_table, send + lo, n * sizeof(double));
+    if (hipMemcpyAsync(c->d_table, c->h_table, n * sizeof(double), hipMemcpyHostToDevice, stream) != hipSuccess) {
       c->err = "suma_dist_allreduce_sum: upload failed";
       return SUMA_ERR_HIP;
     }
-    ncclResult_t r = ncclAllReduce(c->d_send, c->d_recv, n, ncclDouble, ncclSum, c->comm, stream);
+    ncclResult_t r = ncclAllReduce(c->d_table, c->d_table, n, ncclDouble, ncclSum, c->comm, stream);
     if (r != ncclSuccess) {
       c->err = std::string("ncclAllReduce: ") + ncclGetErrorString(r);
       return SUMA_ERR_HIP;
     }
-    double* h_recv = c->h_buf + SUMA_DIST_MAX_DOUBLES;
-    if (hipMemcpyAsync(h_recv, c->d_recv, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+    if (hipMemcpyAsync(c->h_table, c->d_table, n * sizeof(double), hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess) {
       c->err = "suma_dist_allreduce_sum: download failed";
       return SUMA_ERR_HIP;
     }
-    memcpy(out + lo, h_recv, n * sizeof(double));
+    memcpy(out + lo, c->h_table, n * sizeof(double));
   }
   return SUMA_OK;
 }

@@ -121,25 +121,42 @@ extern "C" int suma_run_hypotheses(const suma_params* params, int hip_device, co
   std::vector<suma_icp_stats> stats(mine.size());
   double increment[16];
   for (int i = 0; i < 16; ++i) increment[i] = (i % 5 == 0) ? 1.0 : 0.0;
-  for (uint32_t t = 0; t < job->n_scans && r == SUMA_OK; ++t) {
+  /* A rank that fails must still take part in the NEXT exchange, or its peers wait in the collective for ever (round-3
+   * advisor): it stops working on its pipeline, sends a table whose every row carries NaN in the residual column, every
+   * rank sees the NaN in the summed table and all of them leave at the same scan. */
+  int failed = SUMA_OK;
+  auto fail_local = [&](int code) {
+    if (failed == SUMA_OK) {
+      failed = code;
+      set_error(error, 160, suma_last_error(suma_pipeline_ctx(s)));
+    }
+  };
+  for (uint32_t t = 0; t < job->n_scans; ++t) {
     const suma_scan_ref& sc = job->scans[t];
-    r = job->on_device ? suma_pipeline_begin_scan_device(s, sc.points, sc.labels, sc.probs, sc.n)
-                       : suma_pipeline_begin_scan(s, sc.points, sc.labels, sc.probs, sc.n);
-    if (r != SUMA_OK) break;
+    if (failed == SUMA_OK) {
+      r = job->on_device ? suma_pipeline_begin_scan_device(s, sc.points, sc.labels, sc.probs, sc.n)
+                         : suma_pipeline_begin_scan(s, sc.points, sc.labels, sc.probs, sc.n);
+      if (r != SUMA_OK) fail_local(r);
+    }
+    if (failed != SUMA_OK && job->world == 1) break;
     int32_t win = -1;
     if (t > 0) {
       std::fill(local.begin(), local.end(), 0.0);
-      if (!mine.empty()) {
+      if (failed == SUMA_OK && !mine.empty()) {
         for (size_t j = 0; j < mine.size(); ++j) mul4(increment, job->perturbations + 16 * (size_t)mine[j], &starts[16 * j]);
-        r = suma_pipeline_minimize_hypotheses(s, starts.data(), (uint32_t)mine.size(), fixed_iterations, Ts.data(),
-                                              stats.data());
-        if (r != SUMA_OK) break;
-        for (size_t j = 0; j < mine.size(); ++j) {
-          double* row = &local[18 * (size_t)mine[j]];
-          memcpy(row, &Ts[16 * j], 16 * sizeof(double));
-          row[16] = stats[j].error;
-          row[17] = (double)stats[j].valid;
-        }
+        r = suma_pipeline_minimize_hypotheses(s, starts.data(), (uint32_t)mine.size(), fixed_iterations, Ts.data(), stats.data());
+        if (r != SUMA_OK) fail_local(r);
+        if (failed == SUMA_OK)
+          for (size_t j = 0; j < mine.size(); ++j) {
+            double* row = &local[18 * (size_t)mine[j]];
+            memcpy(row, &Ts[16 * j], 16 * sizeof(double));
+            row[16] = stats[j].error;
+            row[17] = (double)stats[j].valid;
+          }
+      }
+      if (failed != SUMA_OK) {
+        if (job->world == 1) break;
+        for (uint32_t k = 0; k < n_hyp; ++k) local[18 * (size_t)k + 16] = __builtin_nan("");
       }
       if (job->world > 1) {
         r = exchange(user, local.data(), all.data(), 18 * n_hyp);
@@ -147,6 +164,13 @@ extern "C" int suma_run_hypotheses(const suma_params* params, int hip_device, co
           set_error(error, 160, "exchange callback failed");
           suma_pipeline_destroy(s);
           return r;
+        }
+        bool poisoned = false;
+        for (uint32_t k = 0; k < n_hyp; ++k) poisoned = poisoned || (all[18 * (size_t)k + 16] != all[18 * (size_t)k + 16]);
+        if (poisoned) { /* some rank failed: everybody leaves here, the failing rank with its own error text */
+          if (failed == SUMA_OK) set_error(error, 160, "another rank reported an error in the hypothesis exchange");
+          suma_pipeline_destroy(s);
+          return failed != SUMA_OK ? failed : SUMA_ERR_HIP;
         }
       } else {
         all = local;
@@ -163,17 +187,25 @@ extern "C" int suma_run_hypotheses(const suma_params* params, int hip_device, co
       }
       memcpy(increment, &all[18 * (size_t)win], sizeof(increment));
       r = suma_pipeline_apply_increment(s, increment);
-    } else {
+      if (r != SUMA_OK) fail_local(r);
+    } else if (failed == SUMA_OK) {
       r = suma_pipeline_update_pose(s, fixed_iterations); /* first scan: nothing to register against (:190) */
+      if (r != SUMA_OK) fail_local(r);
     }
-    if (r != SUMA_OK) break;
-    r = suma_pipeline_update_map(s);
-    if (r != SUMA_OK) break;
-    winners[t] = win;
-    suma_pipeline_pose(s, poses + 16 * (size_t)t);
+    if (failed == SUMA_OK) {
+      r = suma_pipeline_update_map(s);
+      if (r != SUMA_OK) fail_local(r);
+    }
+    if (failed == SUMA_OK) {
+      winners[t] = win;
+      suma_pipeline_pose(s, poses + 16 * (size_t)t);
+    }
   }
-  if (r == SUMA_OK) r = suma_synchronize(suma_pipeline_ctx(s));
-  if (r != SUMA_OK) set_error(error, 160, suma_last_error(suma_pipeline_ctx(s)));
+  r = failed;
+  if (r == SUMA_OK) {
+    r = suma_synchronize(suma_pipeline_ctx(s));
+    if (r != SUMA_OK) set_error(error, 160, suma_last_error(suma_pipeline_ctx(s)));
+  }
   suma_pipeline_destroy(s);
   return r;
 }

@@ -1,0 +1,39 @@
+"""GPU test (run with -m gpu on an MI355X): the HIP surfel renderer against images made by A REAL OPENGL IMPLEMENTATION
+running the reference's own render_surfels.{vert,geom,frag} (tests/golden/gl_render_450x32.npz, generated with Mesa
+llvmpipe by tests/golden/make_gl_golden.py; the file carries the map, so neither Mesa nor /root/reference is needed
+here).  The GL driver's transcendentals / FMA contraction / attribute interpolation differ from include/suma_detmath.h in
+the last ulps, so this is an agreement bar (>= 97 % of the texels carry the same surfel, as for the oracle in
+tests/test_gl_reference.py), on top of the bit-for-bit comparison with the oracle on the same map."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_bit_equal
+from semantic_suma_amd.types import params_with_size
+
+pytestmark = pytest.mark.gpu
+
+
+def test_hip_render_agrees_with_opengl(oracle_lib):
+    from semantic_suma_amd import core
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gl_render_450x32.npz"))
+    p = params_with_size(int(z["W"]), int(z["H"]))
+    ctx = core.Context(p)
+    smap = core.SurfelMap(ctx)
+    smap.upload(z["surfels"], int(z["timestamp"]))
+    smap.updatePoses(z["poses"].reshape(-1, 4, 4).transpose(0, 2, 1))
+    smap.render_active(z["pose"], float(z["conf_threshold"]))
+    v = smap.newMapFrame().download(0)
+    va, vb = v[..., 3] > 0.5, z["gl_vertex"][..., 3] > 0.5
+    same = va & vb & np.all(np.abs(v - z["gl_vertex"]) <= 1e-4 * (1.0 + np.abs(v)), axis=-1)
+    assert vb.sum() > 5000 and same.sum() >= 0.97 * max(va.sum(), vb.sum()), (same.sum(), va.sum(), vb.sum())
+    n = smap.newMapFrame().download(1)
+    assert np.all(np.abs(n[same] - z["gl_normal"][same]) <= 1e-4)
+    # and the oracle, bit for bit, on the same map
+    ora = oracle_lib.Oracle(p)
+    ora.map_upload(z["surfels"], int(z["timestamp"]))
+    ora.map_update_poses(z["poses"].reshape(-1, 4, 4).transpose(0, 2, 1))
+    ora.map_render_active(z["pose"], float(z["conf_threshold"]))
+    assert_bit_equal(v, ora.map_frame(1).map(0), "render_active vertex map")
+    assert_bit_equal(n, ora.map_frame(1).map(1), "render_active normal map")
