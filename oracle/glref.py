@@ -445,3 +445,79 @@ def limits():
     v = i32(0)
     g.fn("glGetIntegerv", None, u32, C.POINTER(i32))(GL["SUBPIXEL_BITS"], C.byref(v))
     return {"version": g.version, "renderer": g.renderer, "subpixel_bits": v.value}
+
+
+class Sampler:
+    """glow::GlSampler of Frame2Model (Frame2Model.cpp:99-109): CLAMP_TO_BORDER, LINEAR or NEAREST, one object on all units"""
+
+    def __init__(self, linear):
+        g = Context.get()
+        self.g, self.id = g, gen("Samplers")
+        sp = g.fn("glSamplerParameteri", None, u32, u32, i32)
+        f = GL["LINEAR"] if linear else GL["NEAREST"]
+        for pname, val in ((GL["TEXTURE_MIN_FILTER"], f), (GL["TEXTURE_MAG_FILTER"], f), (GL["TEXTURE_WRAP_S"], GL["CLAMP_TO_BORDER"]),
+                           (GL["TEXTURE_WRAP_T"], GL["CLAMP_TO_BORDER"])):
+            sp(self.id, pname, val)
+
+    def bind(self, unit):
+        self.g.fn("glBindSampler", None, u32, u32)(unit, self.id)
+
+
+class Jacobians:
+    """Frame2Model::jacobianProducts (Frame2Model.cpp:14-63 set-up, :136-261 the call) with the reference's
+    Frame2Model_jacobians.{vert,geom,frag}: ceil(W / 64) * H points, each geometry-shader invocation walks 64 texels and
+    emits 16 points into a 2 x 8 RGB32F target with GL_ONE / GL_ONE blending.  Returns the 48 floats the host reads
+    back (:214-227 unpacks them)."""
+
+    def __init__(self, params, entries_per_kernel=64):
+        import math
+        p = self.p = params
+        self.epk = entries_per_kernel
+        self.W, self.H = p.data_width, p.data_height
+        self.prog = Program({"VERTEX_SHADER": "Frame2Model_jacobians.vert", "GEOMETRY_SHADER": "Frame2Model_jacobians.geom",
+                             "FRAGMENT_SHADER": "Frame2Model_jacobians.frag"})
+        self.prog.set(vertex_model=0, normal_model=1, vertex_data=2, normal_data=3, semantic_model=4, semantic_data=5,
+                      entries_per_kernel=int(entries_per_kernel))
+        fov_up, fov_down = abs(float(np.float32(p.data_fov_up))), abs(float(np.float32(p.data_fov_down)))
+        self.prog.set(distance_outliers=bool(p.weight_function == 0), weight_function=int(p.weight_function),
+                      factor=float(p.factor), distance_thresh=float(p.icp_max_distance),
+                      angle_thresh=float(np.float32(math.cos(float(np.float32(p.icp_max_angle)) * math.pi / 180.0))),
+                      fov_up=fov_up, fov_down=fov_down, fov=float(np.float32(fov_up) + np.float32(fov_down)),
+                      min_depth=float(p.min_depth), max_depth=float(p.max_depth), cutoff_threshold=0.0)
+        coords = np.array([(i + 0.5, j + 0.5) for i in range(0, self.W, entries_per_kernel) for j in range(self.H)], dtype=np.float32)
+        self.n = coords.shape[0]
+        g = Context.get()
+        self.vbo = Buffer(coords)
+        self.vao = gen("VertexArrays")
+        g.fn("glBindVertexArray", None, u32)(self.vao)
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], self.vbo.id)
+        g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)(0, 2, GL["FLOAT"], 0, 8, 0)
+        g.fn("glEnableVertexAttribArray", None, u32)(0)
+        self.sampler = Sampler(bool(p.bilinear_sampling))
+        self.target = RectTexture(2, 8)   # RGBA32F here; the reference's RGB_FLOAT target has no alpha to blend either
+        self.fbo = Framebuffer(2, 8)
+
+    def run(self, cur, model, pose, iteration):
+        """cur / model: three (H, W, 4) maps each (vertex, normal, semantic)"""
+        g = Context.get()
+        tex = [RectTexture(m.shape[1], m.shape[0], m) for m in (model[0], model[1], cur[0], cur[1], model[2], cur[2])]
+        g.fn("glPointSize", None, f32)(1.0)
+        g.fn("glClearColor", None, f32, f32, f32, f32)(0, 0, 0, 0)
+        g.fn("glDisable", None, u32)(GL["DEPTH_TEST"])
+        for unit, t in enumerate(tex):
+            t.bind(unit)
+            self.sampler.bind(unit)
+        self.fbo.attach([self.target])
+        g.fn("glViewport", None, i32, i32, i32, i32)(0, 0, 2, 8)
+        clear()
+        g.fn("glEnable", None, u32)(GL["BLEND"])
+        g.fn("glBlendFunc", None, u32, u32)(GL["ONE"], GL["ONE"])
+        self.prog.set(pose=np.asarray(pose, dtype=np.float64).astype(np.float32), iteration=int(iteration))
+        self.prog.use()
+        draw_points(self.vao, self.n)
+        g.fn("glDisable", None, u32)(GL["BLEND"])
+        g.fn("glFinish", None)()
+        g.check("Frame2Model_jacobians draw")
+        for unit in range(6):
+            g.fn("glBindSampler", None, u32, u32)(unit, 0)
+        return self.target.read()[..., :3].reshape(-1)  # 8 rows x 2 texels x RGB = 48 floats, PixelFormat::RGB download

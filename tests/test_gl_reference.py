@@ -156,3 +156,34 @@ def test_committed_gl_golden_is_reproduced_by_the_oracle():
     va, vb = v[..., 3] > 0.5, z["gl_vertex"][..., 3] > 0.5
     same = va & vb & np.all(np.abs(v - z["gl_vertex"]) <= 1e-4 * (1.0 + np.abs(v)), axis=-1)
     assert vb.sum() > 5000 and same.sum() >= 0.97 * max(va.sum(), vb.sum())
+
+
+def test_reference_jacobian_shaders_in_gl(gl, oracle_lib):
+    """Frame2Model::jacobianProducts through the reference's own Frame2Model_jacobians.{vert,geom,frag} in llvmpipe:
+    LINEAR rectangle samplers with CLAMP_TO_BORDER on all six maps, 16 points per geometry-shader invocation blended
+    (GL_ONE, GL_ONE) into the 2 x 8 RGB32F target, unpacked as Frame2Model.cpp:214-227.  This pins the conventions the
+    oracle's K6 rests on -- texel centres at integer + 0.5, the four-tap weights, border colour 0, the layout of the 48
+    floats, Huber from iteration 0 / Tukey from 1 -- against a real GL.  The sums are fp32 and order dependent in GL
+    (exact 2^-28 fixed point in the oracle) and a handful of pairs sit on a gate, so: counters within 0.5 %, F within
+    1 %, the diagonal of J^T W J within 3e-3 relative (measured 1.5e-3: three of 7797 pairs fall the other side of a gate)."""
+    p = params_with_size(W)
+    ora = oracle_lib.Oracle(p)
+    frames = []
+    for k in range(2):
+        pts, lab, prob, _ = get_scan(k, W, True)
+        frames.append(ora.preprocess(pts, lab, prob, k, ora.frame()))
+    T = np.eye(4)
+    T[0, 3] = 0.9
+    J = gl.Jacobians(p)
+    for iteration in (0, 1):
+        b = J.run([frames[1].map(m) for m in range(3)], [frames[0].map(m) for m in range(3)], T, iteration)
+        F, acc, JtJ, Jtr, st = ora.jacobian_products(frames[1], frames[0], T, iteration)
+        valid, Fg, outlier, invalid = b[42], b[43], b[44], b[46]
+        assert st.valid > 5000
+        assert abs(valid - st.valid) <= 0.005 * st.valid and abs(outlier - st.outlier) <= 0.005 * st.valid
+        assert valid + invalid == W * H and abs(invalid - st.invalid) <= 0.005 * st.valid
+        assert abs(Fg - F) <= 0.01 * F
+        JtJ_gl = b[:36].reshape(6, 6)
+        assert np.allclose(np.diag(JtJ_gl), np.diag(JtJ), rtol=3e-3)
+        assert np.allclose(JtJ_gl, JtJ, rtol=0, atol=2e-4 * np.abs(JtJ).max())
+        assert np.allclose(b[36:42], Jtr, rtol=0, atol=0.01 * np.abs(Jtr).max())
