@@ -22,4 +22,10 @@ SUMA_SEQ_CONCURRENT=2 timeout 400 python bench.py --mode sequences11 2>/dev/null
 timeout 300 python bench.py --mode adapter --adapter-scans 300 2>/dev/null | tail -1 > "$O/adapter_path_300_scans.json"
 timeout 300 python tools/ingest_bench.py 2>/dev/null | tail -1 > "$O/ingest.json"
 timeout 300 python tools/multi_seq.py 4 60 2>/dev/null | tail -1 > "$O/multi_seq.txt"
+# round 4: N = 2 ranks started by bench.py itself (gloo, both on this box's one GPU), the per-block phase timeline, the
+# Gauss-Newton station timeline, the HIP <-> GL interop probe
+SUMA_BENCH_FORCE_DEVICE=0 timeout 300 python bench.py --gpus 2 --backend gloo --steps 20 --cpu-scans 0 --adapter-scans 0 --no-kernel-events 2>/dev/null | tail -1 > "$O/bench_gpus2_self_launched_gloo.json"
+timeout 300 python tools/phase_timeline.py 250 30 2>&1 | tail -19 > "$O/phase_timeline.txt"
+timeout 300 python tools/gn_timeline.py 2>&1 | tail -14 > "$O/gn_timeline.txt"
+(g++ -std=c++11 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/gl_interop_probe.cpp -o /tmp/gl_probe -Lsemantic_suma_amd -lsuma_hip -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,$PWD/semantic_suma_amd -Wl,-rpath,/opt/rocm/lib && /tmp/gl_probe) > "$O/gl_interop_probe.txt" 2>&1
 cat "$O/pytest_gpu.txt"; cut -c1-400 "$O/bench.json"; cut -c1-300 "$O/bench_full_sequence_4541.json"; ls "$O"
