@@ -164,63 +164,58 @@ extern "C" int suma_debug_k4_phases(unsigned long long* host, int reset) {
 #define RENDER_WAVES (RENDER_THREADS / 64)
 #define RENDER_BATCH 2
 #define SUMA_RENDER_MAX_BLOCKS 65536u
-/* surfels per lane and trip (round 4).  With one surfel per lane a tile of 256 surfels leaves ~110 candidates: phase 1b
- * runs on two of the block's four waves, and the trip's fixed costs -- five barriers, the block prefix, the tail of
- * the pixel loop -- are paid per 256 surfels.  With two, the candidate list of a trip holds ~220 entries (phase 1b and
- * the pixel loop run on full waves) and the fixed costs are paid per 512 surfels. */
-#ifndef RENDER_PER
-#define RENDER_PER 2
-#endif
-#define RENDER_TILE (RENDER_THREADS * RENDER_PER)
 
-#if RENDER_PER == 1
-#define RENDER_MIN_WAVES 5 /* 96 VGPRs: five 28 KB blocks per CU */
-#else
-#define RENDER_MIN_WAVES 4 /* 128 VGPRs: four 37 KB blocks per CU */
-#endif
-__global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(RENDER_MIN_WAVES, 8))) k_render(RenderArgs a) {
-  __shared__ float s_cand[RENDER_TILE][9];      /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
+/* exclusive rank of `flag` among the block's threads + block total (all threads call) */
+__device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, uint32_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ball = __ballot(flag);
+  if (lane == 0) s_w[wave] = __popcll(ball);
+  __syncthreads();
+  uint32_t off = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < RENDER_WAVES; ++w) {
+    uint32_t c = s_w[w];
+    if (w < wave) off += c;
+    tot += c;
+  }
+  *total = tot;
+  return off + __popcll(ball & ((1ull << lane) - 1ull));
+}
+
+__global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
+  __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
   __shared__ int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
   __shared__ uint32_t s_incl[RENDER_THREADS];
-  __shared__ uint32_t s_w2[RENDER_WAVES];
-  __shared__ uint8_t s_mask[RENDER_TILE]; /* slot mask of a candidate, by list position */
-  /* length of the candidate list, three words used in rotation: trip t appends with LDS atomics to word t % 3 (one
-   * wave-aggregated ds_add_rtn per wave -- the list order is immaterial, the z-buffer keys decide), thread 0 zeroes word
-   * (t + 1) % 3 before the trip's barrier (its last readers passed the barrier of trip t - 1, its next writers wait for
-   * the barrier of trip t).  Round 3 ranked the candidates with ballots + per-wave counters behind a barrier of its own. */
-  __shared__ uint32_t s_ncand[3];
+  __shared__ uint32_t s_w[2][RENDER_WAVES], s_w2[RENDER_WAVES];
+  __shared__ uint8_t s_mask[RENDER_THREADS]; /* slot mask of a candidate, by candidate rank */
   const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 3) s_ncand[threadIdx.x] = 0;
-  __syncthreads();
   /* Tiles are taken from the END of the surfel array first: the array is in creation order, so its tail holds
    * the surfels around the sensor's recent positions -- the ones in view, with pixel tests to run -- and its
    * head mostly surfels that leave after phase 1a.  Dispatching the expensive tiles first keeps the cheap
    * ones for the kernel's tail. */
-  const uint32_t ntile = (S + RENDER_TILE - 1) / RENDER_TILE;
+  const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
   const int npass = a.merged ? 1 : 2;
-  uint32_t trip = 0; /* counts candidate lists */
+  uint32_t trip = 0; /* counts rank barriers: the per-wave counters alternate between two sets (see the early-out) */
   PH_BEGIN;
   for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     PH(7); /* loop overhead / previous tile's tail */
-    const uint32_t blk0 = (ntile - 1u - tile) * RENDER_TILE;
-    float4 s0[RENDER_PER], s1[RENDER_PER], s2[RENDER_PER];
-    bool live[RENDER_PER];
-#pragma unroll
-    for (int u = 0; u < RENDER_PER; ++u) {
-      const uint32_t i = blk0 + (uint32_t)u * RENDER_THREADS + threadIdx.x;
-      s0[u] = s1[u] = s2[u] = f4(0, 0, 0, 0);
-      live[u] = false;
-      if (i < S) {
-        s0[u] = sf[4 * (size_t)i];
-        s1[u] = sf[4 * (size_t)i + 1];
-        s2[u] = sf[4 * (size_t)i + 2];
-        live[u] = !(a.use_stability && !(s1[u].w > a.conf_threshold));
-      }
+    const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
+    const uint32_t i = blk0 + threadIdx.x;
+    float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
+    bool live = false;
+    if (i < S) {
+      s0 = sf[4 * (size_t)i];
+      s1 = sf[4 * (size_t)i + 1];
+      s2 = sf[4 * (size_t)i + 2];
+      live = !(a.use_stability && !(s1.w > a.conf_threshold));
     }
+    const float radius = s0.w, count = s2.w;
+    const int32_t creation = (int32_t)count;
+    const int32_t ts = (int32_t)__float_as_uint(s2.x);
 #ifdef SUMA_PHASE_TIMING
-    if (live[0] && __float_as_uint(s2[RENDER_PER - 1].x) == 0x7fffffffu) ph_acc[7] += 1; /* consumes the loads before the stamp */
+    if (live && ts == 0x7fffffff) ph_acc[7] += 1; /* consumes the loads before the stamp */
 #endif
     PH(0); /* surfel loads arrived */
     for (int sl = 0; sl < npass; ++sl) {
@@ -228,264 +223,235 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       const RenderSlot& slot = a.slot[a.merged ? 1 : sl];
       if (!a.merged && !slot.enabled) continue; /* kernel-uniform */
       const float* inv_pose = (sl == 0 && a.inv_pose_dev != nullptr) ? a.inv_pose_dev : slot.inv_pose.m;
-      uint32_t* const n_list = &s_ncand[trip % 3u];
-      if (threadIdx.x == 0) s_ncand[(trip + 1u) % 3u] = 0;
-      trip += 1;
-      /* ---- phase 1a: RENDER_PER surfels per lane, each appended to the candidate list as soon as it is known ---- */
-      unsigned long long k7_key[RENDER_PER];
-      uint32_t k7_pix[RENDER_PER];
-#pragma unroll
-      for (int u = 0; u < RENDER_PER; ++u) {
-        const uint32_t i = blk0 + (uint32_t)u * RENDER_THREADS + threadIdx.x;
-        const float radius = s0[u].w, count = s2[u].w;
-        const int32_t creation = (int32_t)count;
-        const int32_t ts = (int32_t)__float_as_uint(s2[u].x);
-        uint32_t selmask; /* bit b: the record renders into slot[b].zbuf */
-        {
-          const bool sel_old = live[u] && (creation < a.thr), sel_new = live[u] && (creation >= a.thr || ts >= a.thr);
-          if (a.merged)
-            selmask = ((sel_old && a.slot[0].enabled) ? 1u : 0u) | (sel_new ? 2u : 0u);
-          else
-            selmask = ((slot.mode == 0) ? sel_old : sel_new) ? (1u << sl) : 0u;
-        }
-        const bool selected = selmask != 0;
-        const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
-        bool cand = false;
-        k7_key[u] = SUMA_EMPTY_KEY;
-        k7_pix[u] = 0;
-        v3 p = mk3(0, 0, 0), n = p;
-        float ppx = 0.f;
-        if (selected || k7) {
-          surfel_to_sensor(a.poses, inv_pose, count, xyz(s0[u]), xyz(s1[u]), &p, &n);
-          float lp = len3(p);
-          if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
-            v3 pp = mk3(0, 0, 0);
-            if (selected || a.k7_same_proj) pp = project01(a.q, p);
-            if (k7) {
-              /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
-              const v3 pr = a.k7_same_proj ? pp : project01(a.k7_q, p);
-              float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
-              float zn = 2.0f * pr.z - 1.0f;
-              if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
-                /* depth-tested write deferred to phase 2, where its memory round trip overlaps the raster's */
-                k7_key[u] = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
-                k7_pix[u] = (uint32_t)(int32_t)fy * (uint32_t)a.k7_q.W + (uint32_t)(int32_t)fx;
-              }
-            }
-            if (selected) {
-              cand = (pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f);
-              ppx = pp.x;
+      /* ---- phase 1a ---- */
+      uint32_t selmask; /* bit b: the record renders into slot[b].zbuf */
+      {
+        const bool sel_old = live && (creation < a.thr), sel_new = live && (creation >= a.thr || ts >= a.thr);
+        if (a.merged)
+          selmask = ((sel_old && a.slot[0].enabled) ? 1u : 0u) | (sel_new ? 2u : 0u);
+        else
+          selmask = ((slot.mode == 0) ? sel_old : sel_new) ? (1u << sl) : 0u;
+      }
+      const bool selected = selmask != 0;
+      const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
+      bool cand = false;
+      unsigned long long k7_key = SUMA_EMPTY_KEY;
+      uint32_t k7_pix = 0;
+      v3 p = mk3(0, 0, 0), n = p;
+      float ppx = 0.f;
+      if (selected || k7) {
+        surfel_to_sensor(a.poses, inv_pose, count, xyz(s0), xyz(s1), &p, &n);
+        float lp = len3(p);
+        if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
+          v3 pp = mk3(0, 0, 0);
+          if (selected || a.k7_same_proj) pp = project01(a.q, p);
+          if (k7) {
+            /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
+            const v3 pr = a.k7_same_proj ? pp : project01(a.k7_q, p);
+            float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
+            float zn = 2.0f * pr.z - 1.0f;
+            if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
+              /* depth-tested write deferred to phase 2, where its memory round trip overlaps the raster's */
+              k7_key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
+              k7_pix = (uint32_t)(int32_t)fy * (uint32_t)a.k7_q.W + (uint32_t)(int32_t)fx;
             }
           }
-        }
-        const unsigned long long cb = __ballot(cand);
-        if (cb != 0ull) { /* wave-uniform */
-          uint32_t base = 0;
-          if (lane == 0) base = __hip_atomic_fetch_add(n_list, (uint32_t)__popcll(cb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-          if (cand) {
-            const uint32_t pos = base + (uint32_t)__popcll(cb & ((1ull << lane) - 1ull));
-            float* r = s_cand[pos];
-            r[0] = p.x;
-            r[1] = p.y;
-            r[2] = p.z;
-            r[3] = n.x;
-            r[4] = n.y;
-            r[5] = n.z;
-            r[6] = radius;
-            r[7] = ppx;
-            r[8] = __uint_as_float(i);
-            s_mask[pos] = (uint8_t)selmask;
+          if (selected) {
+            cand = (pp.x >= 0.0f && pp.y >= 0.0f && pp.z >= 0.0f && pp.x < 1.0f && pp.y < 1.0f && pp.z < 1.0f);
+            ppx = pp.x;
           }
         }
       }
-      __syncthreads();
-      const uint32_t ncand = *n_list;
-      PH(1); /* phase 1a + candidate list + barrier */
+      uint32_t ncand;
+      const uint32_t crank = render_block_rank(cand, s_w[trip & 1u], &ncand);
+      trip += 1;
+      PH(1); /* phase 1a + rank barrier */
       if (ncand == 0) {
-        /* Nothing of this tile renders into this slot (block-uniform) -- the rule for the "old" slot of render()
-         * outside loop closures, and for tiles that are out of view: no corners, no prefix, no closing barrier.  The
-         * next trip appends to another counter word and nobody reads the list. */
-#pragma unroll
-        for (int u = 0; u < RENDER_PER; ++u)
-          if (k7_key[u] != SUMA_EMPTY_KEY) zbuf_min(&a.k7_zbuf[k7_pix[u]], k7_key[u]);
+        /* Nothing of this tile renders into this slot (block-uniform: every thread totals the same counters) --
+         * the rule for the "old" slot of render() outside loop closures, and for tiles that are out of view: no
+         * candidate list, no prefix, no closing barrier.  The LDS lists are untouched; the rank counters of the next
+         * trip live in the other set, and that trip's barrier separates this trip's reads from the set's next use. */
+        if (k7_key != SUMA_EMPTY_KEY) zbuf_min(&a.k7_zbuf[k7_pix], k7_key);
         continue;
       }
-      PH(2);
-      unsigned long long k7_cur[RENDER_PER];
-      unsigned long long* const zb0 = a.slot[0].zbuf;
-      unsigned long long* const zb1 = a.slot[1].zbuf;
-      for (uint32_t cbase = 0; cbase < ncand; cbase += RENDER_THREADS) { /* block-uniform: usually one round */
-        /* ---- phase 1b: dense lanes ---- */
-        uint32_t ntests = 0;
-        const uint32_t ci = cbase + threadIdx.x;
-        if (ci < ncand) {
-          const float* r = s_cand[ci];
-          const v3 cp = mk3(r[0], r[1], r[2]), cn = mk3(r[3], r[4], r[5]);
-          const float crad = r[6], cppx = r[7];
-          v3 u = normalize3(mk3(cn.y - cn.z, -cn.x, cn.x));
-          v3 v = normalize3(cross3(cn, u));
-          v3 ru = scale3(crad, u), rv = scale3(crad, v);
-          v3 corner[4];
-          corner[0] = sub3(sub3(cp, ru), rv);
-          corner[1] = sub3(add3(cp, ru), rv);
-          corner[2] = add3(sub3(cp, ru), rv);
-          corner[3] = add3(add3(cp, ru), rv);
-          /* The spherical projection of the corners is evaluated in two halves: first range + pitch
-           * (image row), and the yaw (atan2, image column) only if the rows spanned by the quad contain
-           * a pixel-centre row at all -- at 64 rows over 28 degrees about half of the quads do not.
-           * Identical values to project01(), just not computed when they cannot matter. */
-          int32_t X[4], Y[4];
-          float Z[4];
-          bool bad = false;
+      if (cand) {
+        float* r = s_cand[crank];
+        r[0] = p.x;
+        r[1] = p.y;
+        r[2] = p.z;
+        r[3] = n.x;
+        r[4] = n.y;
+        r[5] = n.z;
+        r[6] = radius;
+        r[7] = ppx;
+        r[8] = __uint_as_float(i);
+        s_mask[crank] = (uint8_t)selmask;
+      }
+      __syncthreads();
+      PH(2); /* candidate list written + barrier */
+      /* ---- phase 1b: dense lanes ---- */
+      uint32_t ntests = 0;
+      if (threadIdx.x < ncand) {
+        const float* r = s_cand[threadIdx.x];
+        const v3 cp = mk3(r[0], r[1], r[2]), cn = mk3(r[3], r[4], r[5]);
+        const float crad = r[6], cppx = r[7];
+        v3 u = normalize3(mk3(cn.y - cn.z, -cn.x, cn.x));
+        v3 v = normalize3(cross3(cn, u));
+        v3 ru = scale3(crad, u), rv = scale3(crad, v);
+        v3 corner[4];
+        corner[0] = sub3(sub3(cp, ru), rv);
+        corner[1] = sub3(add3(cp, ru), rv);
+        corner[2] = add3(sub3(cp, ru), rv);
+        corner[3] = add3(add3(cp, ru), rv);
+        /* The spherical projection of the corners is evaluated in two halves: first range + pitch
+         * (image row), and the yaw (atan2, image column) only if the rows spanned by the quad contain
+         * a pixel-centre row at all -- at 64 rows over 28 degrees about half of the quads do not.
+         * Identical values to project01(), just not computed when they cannot matter. */
+        int32_t X[4], Y[4];
+        float Z[4];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float depth = len3(corner[k]);
+          const float pitch = -sdm_asin(corner[k].z / depth);
+          const float y01 = 1.0f - ((pitch * SUMA_RAD2DEG_F) + a.q.fov_up) / a.q.fov;
+          /* window depth as shader (gl_Position.z = 2 z01 - 1, render_surfels.geom:104-117) and viewport (z_w = 0.5 z_ndc +
+           * 0.5) form it: in fp32 that is z01 again for only 84 % of the values */
+          Z[k] = 0.5f * (2.0f * ((depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth)) - 1.0f) + 0.5f;
+          const float yw = y01 * a.q.height;
+          if (sdm_isnan(yw) || sdm_isnan(Z[k])) bad = true;
+          Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
+        }
+        const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
+        int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8; /* pixel-centre rows inside the box */
+        j0 = max(j0, 0);
+        j1 = min(j1, a.q.H - 1);
+        if (!bad && j0 <= j1) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float depth = len3(corner[k]);
-            const float pitch = -sdm_asin(corner[k].z / depth);
-            const float y01 = 1.0f - ((pitch * SUMA_RAD2DEG_F) + a.q.fov_up) / a.q.fov;
-            /* window depth as shader (gl_Position.z = 2 z01 - 1, render_surfels.geom:104-117) and viewport (z_w = 0.5 z_ndc +
-             * 0.5) form it: in fp32 that is z01 again for only 84 % of the values */
-            Z[k] = 0.5f * (2.0f * ((depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth)) - 1.0f) + 0.5f;
-            const float yw = y01 * a.q.height;
-            if (sdm_isnan(yw) || sdm_isnan(Z[k])) bad = true;
-            Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
+            const float yaw = sdm_atan2(corner[k].y, corner[k].x);
+            float x01 = 0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f);
+            /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
+            if (cppx - x01 > 0.5f) x01 += 1.0f;
+            if (x01 - cppx > 0.5f) x01 -= 1.0f;
+            const float xw = x01 * a.q.width;
+            if (sdm_isnan(xw)) bad = true;
+            X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
           }
-          const int32_t minY = min(min(Y[0], Y[1]), min(Y[2], Y[3])), maxY = max(max(Y[0], Y[1]), max(Y[2], Y[3]));
-          int32_t j0 = (minY - 128 + 255) >> 8, j1 = (maxY - 128) >> 8; /* pixel-centre rows inside the box */
-          j0 = max(j0, 0);
-          j1 = min(j1, a.q.H - 1);
-          if (!bad && j0 <= j1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const float yaw = sdm_atan2(corner[k].y, corner[k].x);
-              float x01 = 0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f);
-              /* render_surfels.geom:67-69: keep the quad on the centre's side of the yaw seam */
-              if (cppx - x01 > 0.5f) x01 += 1.0f;
-              if (x01 - cppx > 0.5f) x01 -= 1.0f;
-              const float xw = x01 * a.q.width;
-              if (sdm_isnan(xw)) bad = true;
-              X[k] = (int32_t)sdm_floor(xw * 256.0f + 0.5f);
-            }
-            if (!bad) {
-              const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
-              int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel-centre columns inside the box */
-              i0 = max(i0, 0);
-              i1 = min(i1, a.q.W - 1);
-              if (i0 <= i1) {
-                const int32_t w = i1 - i0 + 1;
-                ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
-                int32_t* q = s_rec[threadIdx.x];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                  q[k] = X[k];
-                  q[4 + k] = Y[k];
-                  q[8 + k] = __float_as_int(Z[k]);
-                }
-                q[12] = i0;
-                q[13] = j0;
-                q[14] = w;
-                q[15] = __float_as_int(r[8]);
-                q[16] = (int32_t)s_mask[ci];
-              }
-            }
-          }
-        }
-        PH(3); /* phase 1b */
-        /* inclusive prefix of the test counts over the block */
-        uint32_t incl = wave_inclusive_scan(ntests);
-        if (lane == 63) s_w2[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < RENDER_WAVES; ++w) {
-          uint32_t c = s_w2[w];
-          if (w < wave) woff += c;
-          total += c;
-        }
-        s_incl[threadIdx.x] = incl + woff;
-        __syncthreads();
-        PH(4); /* prefix over the block, two barriers */
-        /* ---- phase 2 ---- */
-        /* RENDER_BATCH tests per lane and trip: the fragments' keys are computed first, then the (device-
-         * coherent, i.e. memory-side) z-buffer reads of the batch are in flight together and the atomics follow
-         * -- one memory round trip per 512 tests instead of two per 256 (a batch of 4 is 0.5 % slower: 96 VGPRs
-         * and 8 bytes of scratch against 93 and none).  The two strip triangles of a quad
-         * write the same pixel, so their keys are min-combined into a single depth-tested write. */
-        if (cbase == 0) {
-#pragma unroll
-          for (int u = 0; u < RENDER_PER; ++u) {
-            k7_cur[u] = 0;
-            if (k7_key[u] != SUMA_EMPTY_KEY)
-              k7_cur[u] = __hip_atomic_load(&a.k7_zbuf[k7_pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        for (uint32_t t0 = threadIdx.x; t0 < total; t0 += RENDER_BATCH * RENDER_THREADS) {
-          unsigned long long key[RENDER_BATCH];
-          uint32_t pix[RENDER_BATCH], msk[RENDER_BATCH];
-#pragma unroll
-          for (int u = 0; u < RENDER_BATCH; ++u) {
-            const uint32_t t = t0 + (uint32_t)u * RENDER_THREADS;
-            key[u] = SUMA_EMPTY_KEY;
-            pix[u] = 0;
-            msk[u] = 0;
-            if (t < total) {
-              /* source record: the first one whose inclusive prefix exceeds t */
-              int lo = 0, hi = RENDER_THREADS - 1;
-#pragma unroll
-              for (int it = 0; it < 8; ++it) {
-                int mid = (lo + hi) >> 1;
-                if (s_incl[mid] > t)
-                  hi = mid;
-                else
-                  lo = mid + 1;
-              }
-              const int src = lo;
-              const uint32_t excl = src ? s_incl[src - 1] : 0u;
-              const int32_t* r = s_rec[src];
-              const uint32_t q = t - excl, w = (uint32_t)r[14];
-              const uint32_t qj = q / w, qi = q - qj * w;
-              const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
-              rvtx vt[4];
+          if (!bad) {
+            const int32_t minX = min(min(X[0], X[1]), min(X[2], X[3])), maxX = max(max(X[0], X[1]), max(X[2], X[3]));
+            int32_t i0 = (minX - 128 + 255) >> 8, i1 = (maxX - 128) >> 8; /* pixel-centre columns inside the box */
+            i0 = max(i0, 0);
+            i1 = min(i1, a.q.W - 1);
+            if (i0 <= i1) {
+              const int32_t w = i1 - i0 + 1;
+              ntests = (uint32_t)w * (uint32_t)(j1 - j0 + 1);
+              int32_t* q = s_rec[threadIdx.x];
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
-                vt[k].X = r[k];
-                vt[k].Y = r[4 + k];
-                vt[k].z = __int_as_float(r[8 + k]);
-                vt[k].tu = (k & 1) ? 1.0f : -1.0f;
-                vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+                q[k] = X[k];
+                q[4 + k] = Y[k];
+                q[8 + k] = __float_as_int(Z[k]);
               }
-              const uint32_t id = (uint32_t)r[15];
-              /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
-              const unsigned long long ka = raster_key(vt[0], vt[1], vt[2], pi, pj, id, slot.tie);
-              const unsigned long long kb = raster_key(vt[2], vt[1], vt[3], pi, pj, id, slot.tie);
-              key[u] = ka < kb ? ka : kb;
-              pix[u] = (uint32_t)pj * (uint32_t)a.q.W + (uint32_t)pi;
-              msk[u] = (uint32_t)r[16];
+              q[12] = i0;
+              q[13] = j0;
+              q[14] = w;
+              q[15] = __float_as_int(r[8]);
+              q[16] = (int32_t)s_mask[threadIdx.x];
             }
-          }
-          /* a z-buffer a fragment does not go to reads as 0: no key is smaller, no atomic follows */
-          unsigned long long cur0[RENDER_BATCH], cur1[RENDER_BATCH];
-#pragma unroll
-          for (int u = 0; u < RENDER_BATCH; ++u) {
-            cur0[u] = cur1[u] = 0;
-            if (key[u] != SUMA_EMPTY_KEY) {
-              if (msk[u] & 1u) cur0[u] = __hip_atomic_load(&zb0[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              if (msk[u] & 2u) cur1[u] = __hip_atomic_load(&zb1[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < RENDER_BATCH; ++u) {
-            if (key[u] < cur0[u]) atomicMin(&zb0[pix[u]], key[u]);
-            if (key[u] < cur1[u]) atomicMin(&zb1[pix[u]], key[u]);
           }
         }
-        PH(5); /* phase 2: pixel tests, z-buffer reads, atomics */
-        __syncthreads(); /* s_rec / s_incl are reused by the next round, the lists by the next slot / tile */
-        PH(6); /* closing barrier */
       }
+      PH(3); /* phase 1b */
+      /* inclusive prefix of the test counts over the block */
+      uint32_t incl = wave_inclusive_scan(ntests);
+      if (lane == 63) s_w2[wave] = incl;
+      __syncthreads();
+      uint32_t woff = 0, total = 0;
 #pragma unroll
-      for (int u = 0; u < RENDER_PER; ++u)
-        if (k7_key[u] < k7_cur[u]) atomicMin(&a.k7_zbuf[k7_pix[u]], k7_key[u]);
+      for (int w = 0; w < RENDER_WAVES; ++w) {
+        uint32_t c = s_w2[w];
+        if (w < wave) woff += c;
+        total += c;
+      }
+      s_incl[threadIdx.x] = incl + woff;
+      __syncthreads();
+      PH(4); /* prefix over the block, two barriers */
+      /* ---- phase 2 ---- */
+      /* RENDER_BATCH tests per lane and trip: the fragments' keys are computed first, then the (device-
+       * coherent, i.e. memory-side) z-buffer reads of the batch are in flight together and the atomics follow
+       * -- one memory round trip per 512 tests instead of two per 256 (a batch of 4 is 0.5 % slower: 96 VGPRs
+       * and 8 bytes of scratch against 93 and none).  The two strip triangles of a quad
+       * write the same pixel, so their keys are min-combined into a single depth-tested write. */
+      unsigned long long k7_cur = 0;
+      if (k7_key != SUMA_EMPTY_KEY)
+        k7_cur = __hip_atomic_load(&a.k7_zbuf[k7_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned long long* const zb0 = a.slot[0].zbuf;
+      unsigned long long* const zb1 = a.slot[1].zbuf;
+      for (uint32_t t0 = threadIdx.x; t0 < total; t0 += RENDER_BATCH * RENDER_THREADS) {
+        unsigned long long key[RENDER_BATCH];
+        uint32_t pix[RENDER_BATCH], msk[RENDER_BATCH];
+#pragma unroll
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          const uint32_t t = t0 + (uint32_t)u * RENDER_THREADS;
+          key[u] = SUMA_EMPTY_KEY;
+          pix[u] = 0;
+          msk[u] = 0;
+          if (t < total) {
+            /* source record: the first one whose inclusive prefix exceeds t */
+            int lo = 0, hi = RENDER_THREADS - 1;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+              int mid = (lo + hi) >> 1;
+              if (s_incl[mid] > t)
+                hi = mid;
+              else
+                lo = mid + 1;
+            }
+            const int src = lo;
+            const uint32_t excl = src ? s_incl[src - 1] : 0u;
+            const int32_t* r = s_rec[src];
+            const uint32_t q = t - excl, w = (uint32_t)r[14];
+            const uint32_t qj = q / w, qi = q - qj * w;
+            const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
+            rvtx vt[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              vt[k].X = r[k];
+              vt[k].Y = r[4 + k];
+              vt[k].z = __int_as_float(r[8 + k]);
+              vt[k].tu = (k & 1) ? 1.0f : -1.0f;
+              vt[k].tv = (k & 2) ? 1.0f : -1.0f;
+            }
+            const uint32_t id = (uint32_t)r[15];
+            /* triangle strip: (v0,v1,v2), (v2,v1,v3) */
+            const unsigned long long ka = raster_key(vt[0], vt[1], vt[2], pi, pj, id, slot.tie);
+            const unsigned long long kb = raster_key(vt[2], vt[1], vt[3], pi, pj, id, slot.tie);
+            key[u] = ka < kb ? ka : kb;
+            pix[u] = (uint32_t)pj * (uint32_t)a.q.W + (uint32_t)pi;
+            msk[u] = (uint32_t)r[16];
+          }
+        }
+        /* a z-buffer a fragment does not go to reads as 0: no key is smaller, no atomic follows */
+        unsigned long long cur0[RENDER_BATCH], cur1[RENDER_BATCH];
+#pragma unroll
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          cur0[u] = cur1[u] = 0;
+          if (key[u] != SUMA_EMPTY_KEY) {
+            if (msk[u] & 1u) cur0[u] = __hip_atomic_load(&zb0[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (msk[u] & 2u) cur1[u] = __hip_atomic_load(&zb1[pix[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RENDER_BATCH; ++u) {
+          if (key[u] < cur0[u]) atomicMin(&zb0[pix[u]], key[u]);
+          if (key[u] < cur1[u]) atomicMin(&zb1[pix[u]], key[u]);
+        }
+      }
+      if (k7_key < k7_cur) atomicMin(&a.k7_zbuf[k7_pix], k7_key);
+      PH(5); /* phase 2: pixel tests, z-buffer reads, atomics */
+      __syncthreads(); /* the LDS lists are reused by the next slot / iteration */
+      PH(6); /* closing barrier */
     }
   }
   PH_END(g_k4_phase);
@@ -615,7 +581,7 @@ static uint32_t stream_grid(suma_ctx* c) {
   /* sized from the last surfel count the host has seen; the kernels grid-stride over the
    * device-resident count, so a stale value only changes the number of loop trips */
   uint64_t est = (uint64_t)c->known_surfels + 2 * c->P;
-  uint64_t blocks = (est + RENDER_TILE - 1) / RENDER_TILE;
+  uint64_t blocks = (est + 255) / 256;
   /* one tile per block while that stays a sane grid: the per-tile cost varies several-fold (pixel tests),
    * and the hardware dispatcher balances single-tile blocks for free; very large maps fall back to
    * grid-striding */
