@@ -521,3 +521,53 @@ class Jacobians:
         for unit in range(6):
             g.fn("glBindSampler", None, u32, u32)(unit, 0)
         return self.target.read()[..., :3].reshape(-1)  # 8 rows x 2 texels x RGB = 48 floats, PixelFormat::RGB download
+
+
+class VertexMap:
+    """Preprocessing::process, first pass (Preprocessing.cpp:24-60 set-up, :120-189 the draw) with the reference's
+    gen_vertexmap.{vert,frag}: GL_POINTS of size 1 into the vertex map + semantic map, DEPTH24_STENCIL8, GL_LESS.  The
+    label / prob attribute pointers start 4 / 5 floats into their buffers, as the reference sets them
+    (Preprocessing.cpp:142-145, quirk B-1); the buffers are zero-padded so that the fetches stay inside."""
+
+    def __init__(self, params):
+        p = self.p = params
+        self.W, self.H = p.data_width, p.data_height
+        self.prog = Program({"VERTEX_SHADER": "gen_vertexmap.vert", "FRAGMENT_SHADER": "gen_vertexmap.frag"})
+        # Preprocessing::setParameters, Preprocessing.cpp:77-100
+        self.prog.set(width=float(self.W), height=float(self.H), fov_up=abs(float(np.float32(p.data_fov_up))),
+                      fov_down=abs(float(np.float32(p.data_fov_down))), min_depth=float(p.min_depth), max_depth=float(p.max_depth))
+        self.fbo = Framebuffer(self.W, self.H)
+
+    def run(self, points, labels, probs, timestamp, label_offset=4, prob_offset=5):
+        g = Context.get()
+        n = points.shape[0]
+        pts = np.ascontiguousarray(points, dtype=np.float32).reshape(n, 4)
+        lab = np.zeros(n + 8, dtype=np.float32)
+        prb = np.zeros(n + 8, dtype=np.float32)
+        lab[:n] = labels
+        prb[:n] = probs
+        bp, bl, bq = Buffer(pts), Buffer(lab), Buffer(prb)
+        vao = gen("VertexArrays")
+        g.fn("glBindVertexArray", None, u32)(vao)
+        vap = g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)
+        bind = g.fn("glBindBuffer", None, u32, u32)
+        en = g.fn("glEnableVertexAttribArray", None, u32)
+        bind(GL["ARRAY_BUFFER"], bp.id)
+        vap(0, 4, GL["FLOAT"], 0, 16, 0)
+        bind(GL["ARRAY_BUFFER"], bl.id)
+        vap(1, 1, GL["FLOAT"], 0, 4, 4 * label_offset)
+        bind(GL["ARRAY_BUFFER"], bq.id)
+        vap(2, 1, GL["FLOAT"], 0, 4, 4 * prob_offset)
+        for k in range(3):
+            en(k)
+        vmap, smap = RectTexture(self.W, self.H), RectTexture(self.W, self.H)
+        g.fn("glPointSize", None, f32)(1.0)
+        common_state(self.W, self.H, "LESS")
+        self.fbo.attach([vmap, smap])
+        self.prog.set(isfirst=bool(timestamp < 10))
+        self.prog.use()
+        clear()
+        draw_points(vao, n)
+        g.fn("glFinish", None)()
+        g.check("gen_vertexmap draw")
+        return vmap.read(), smap.read()
