@@ -170,6 +170,10 @@ int suma_map_counts(suma_ctx* ctx, uint32_t* n_updated, uint32_t* n_new, uint32_
  * (suma_params.cache_surfels), and how often it has been compacted -- when it runs full the live tiles are copied into
  * a fresh arena; SUMA_ERR_CAPACITY only if the live tiles alone do not fit */
 int suma_map_cache_stats(suma_ctx* ctx, uint32_t* used, uint32_t* capacity, uint32_t* compactions);
+/* one parked tile, as the reference keeps it in submapCache_(i, j).surfels (SurfelMap.h:186, filled by extractSurfels,
+ * SurfelMap.cpp:733-734): *n = its surfels (0 for a tile that was never extracted); the first min(*n, capacity)
+ * records are copied to `host` (may be NULL with capacity 0 to ask for the size) */
+int suma_map_download_cached_tile(suma_ctx* ctx, int32_t i, int32_t j, suma_surfel* host, uint32_t capacity, uint32_t* n);
 
 /* ---- SurfelMapping::processScan (SurfelMapping.h:47, SurfelMapping.cpp:175-210) without the
  *      loop-closure / pose-graph part: initialize, preprocess, updatePose

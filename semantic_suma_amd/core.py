@@ -152,6 +152,7 @@ def lib():
     L.suma_map_download_integrated.argtypes = [vp, vp]
     L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
     L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.suma_map_download_cached_tile.argtypes = [vp, C.c_int32, C.c_int32, vp, u32, C.POINTER(u32)]
     L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
     L.suma_pipeline_destroy.argtypes = [vp]
@@ -636,6 +637,15 @@ class SurfelMap:
         a, b, cc = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
         self.ctx.check(self.ctx.L.suma_map_cache_stats(self.ctx.h, C.byref(a), C.byref(b), C.byref(cc)))
         return a.value, b.value, cc.value
+
+    def cached_tile(self, i: int, j: int) -> np.ndarray:
+        """submapCache_(i, j).surfels (SurfelMap.h:186): the records parked for one tile, (n, 16) float32"""
+        n = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_download_cached_tile(self.ctx.h, i, j, None, 0, C.byref(n)))
+        out = np.zeros((n.value, 16), dtype=np.float32)
+        if n.value:
+            self.ctx.check(self.ctx.L.suma_map_download_cached_tile(self.ctx.h, i, j, _ptr(out), n.value, C.byref(n)))
+        return out
 
     def counts(self):
         """(S' survivors of K9, D new surfels of K10, surfels parked in submap caches, submap origin)"""

@@ -50,21 +50,28 @@ __device__ __forceinline__ unsigned long long st_pack(uint32_t epoch, uint32_t f
  * on words that are not published yet.  Critical path = compute + one publish + one read.
  * Status words carry the launch epoch (never cleared); group accumulators are cleared by the
  * finaliser of each launch (block_leaves_last). */
+/* Every count travels as a PAIR {items selected, items selected that also go to the submap cache}: a tile's
+ * status value is (second << 16) | first (a tile holds at most 4096 items), a group accumulator is
+ * {tiles arrived : 8, sum of second : 24, sum of first : 32}.  Kernels with one count pass second = 0. */
+struct Pair {
+  uint32_t a, x;
+};
 __device__ __forceinline__ void lookback_publish(unsigned long long* __restrict__ status,
                                                  unsigned long long* __restrict__ group, uint32_t tile, uint32_t agg,
-                                                 uint32_t epoch) {
-  __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_fetch_add(&group[tile >> 6], (1ull << 32) | (unsigned long long)agg, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+                                                 uint32_t epoch, uint32_t aggx = 0) {
+  __hip_atomic_store(&status[tile], st_pack(epoch, ST_AGG, (aggx << 16) | agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add(&group[tile >> 6], (1ull << 56) | ((unsigned long long)aggx << 32) | (unsigned long long)agg,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 /* called by one full wave; returns the number of selected items in all tiles before `tile`.
  * Every spin is bounded (SUMA_SPIN_LIMIT polls, seconds of wall time): a protocol error must surface
  * as an error code (DevState.overflow bit 3), never as a hung GPU. */
 #define SUMA_SPIN_LIMIT (1u << 26)
-__device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
-                                     uint32_t tile, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
+template <bool PAIR>
+__device__ Pair lookback_collect2(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
+                                  uint32_t tile, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
   const uint32_t g = tile >> 6;
-  uint32_t sum = 0;
+  uint32_t sum = 0, sumx = 0;
   bool timed_out = false;
   /* complete groups before mine: every group before g holds exactly 64 tiles */
   for (uint32_t gi = lane; gi < g; gi += 64) {
@@ -72,10 +79,11 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
     uint32_t spins = 0;
     for (;;) {
       w = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(w >> 32) == 64u || ++spins >= SUMA_SPIN_LIMIT) break;
+      if ((uint32_t)(w >> 56) == 64u || ++spins >= SUMA_SPIN_LIMIT) break;
     }
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
     sum += (uint32_t)(w & 0xffffffffull);
+    if (PAIR) sumx += (uint32_t)(w >> 32) & 0xffffffu;
   }
   /* earlier tiles of my own group */
   const uint32_t j = tile & 63u;
@@ -87,13 +95,22 @@ __device__ uint32_t lookback_collect(unsigned long long* __restrict__ status, un
       if (!((uint32_t)(w >> 34) != (epoch & 0x3fffffffu) || ((w >> 32) & 3ull) == 0) || ++spins >= SUMA_SPIN_LIMIT) break;
     }
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
-    sum += (uint32_t)(w & 0xffffffffull);
+    sum += (uint32_t)(w & 0xffffull);
+    if (PAIR) sumx += (uint32_t)(w >> 16) & 0xffffu;
   }
   if (timed_out) {
     atomicOr(fault, 8u);
     atomicOr(fault + (offsetof(DevState, fault_site) - offsetof(DevState, overflow)) / 4, 0x2u);
   }
-  return (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(sum), 63); /* wave total, DPP (dev_math.h) */
+  Pair r;
+  r.a = (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(sum), 63); /* wave total, DPP (dev_math.h) */
+  r.x = PAIR ? (uint32_t)__builtin_amdgcn_readlane((int)wave_inclusive_scan(sumx), 63) : 0u;
+  return r;
+}
+__device__ __forceinline__ uint32_t lookback_collect(unsigned long long* __restrict__ status,
+                                                     unsigned long long* __restrict__ group, uint32_t tile, uint32_t epoch,
+                                                     int lane, uint32_t* __restrict__ fault) {
+  return lookback_collect2<false>(status, group, tile, epoch, lane, fault).a;
 }
 __device__ uint32_t lookback_prefix(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
                                     uint32_t tile, uint32_t agg, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
@@ -126,6 +143,33 @@ __device__ __forceinline__ BlockRank block_rank(bool flag, uint32_t* s_wave /* [
   return r;
 }
 
+/* two flags ranked behind one barrier */
+__device__ __forceinline__ void block_rank2(bool fa, bool fb, uint32_t* s_wa, uint32_t* s_wb, BlockRank* ra, BlockRank* rb) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long ba = __ballot(fa), bb = __ballot(fb);
+  const unsigned long long lo = (1ull << lane) - 1ull;
+  if (lane == 0) {
+    s_wa[wave] = __popcll(ba);
+    s_wb[wave] = __popcll(bb);
+  }
+  __syncthreads();
+  uint32_t offa = 0, tota = 0, offb = 0, totb = 0;
+#pragma unroll
+  for (int w = 0; w < (int)TILE_WAVES; ++w) {
+    const uint32_t ca = s_wa[w], cb = s_wb[w];
+    if (w < wave) {
+      offa += ca;
+      offb += cb;
+    }
+    tota += ca;
+    totb += cb;
+  }
+  ra->rank = offa + __popcll(ba & lo);
+  ra->total = tota;
+  rb->rank = offb + __popcll(bb & lo);
+  rb->total = totb;
+}
+
 /* Ticket bookkeeping shared by the compaction kernels.  Every block draws tickets until it gets
  * one >= ntiles; those failing tickets are ntiles .. ntiles + gridDim.x - 1, and a block draws
  * its failing ticket only after it has finished all of its tiles, so the block that draws the
@@ -138,6 +182,24 @@ __device__ __forceinline__ bool is_finaliser(uint32_t failing_ticket, uint32_t n
 __device__ __forceinline__ void finalise_tickets(DevState* ds, unsigned long long* group_next, uint32_t group_words) {
   for (uint32_t gi = threadIdx.x; gi < group_words; gi += blockDim.x) group_next[gi] = 0;
   if (threadIdx.x == 0) ds->ticket = 0;
+}
+
+/* extractSurfels, SurfelMap.cpp:725-739: the tile's block in the cache arena becomes its SubmapCache entry; n = surfels
+ * selected (capacity SurfelMap.cpp:279) */
+__device__ __forceinline__ void commit_extraction(DevState* ds, CacheSlot* slots, uint32_t slot, uint32_t base,
+                                                  uint32_t arena_cap, uint32_t n) {
+  if (n > SUMA_EXTRACT_CAPACITY) {
+    n = SUMA_EXTRACT_CAPACITY;
+    atomicOr(&ds->overflow, 4u);
+  }
+  if ((uint64_t)base + n > arena_cap) {
+    n = arena_cap - base;
+    atomicOr(&ds->overflow, 2u);
+  }
+  slots[slot].offset = base;
+  slots[slot].count = n;
+  ds->cache_used = base + n;
+  ds->n_extracted = n;
 }
 
 /* ---------------------------------------------------------------------------------------------
@@ -204,6 +266,11 @@ struct UpdArgs {
   /* K12 selection riding on K9 / K10: the tile that is extracted right after this update (ex_flags == NULL: none) */
   uint8_t* ex_flags;
   float ex_cx, ex_cy, ex_extent;
+  /* K12 itself riding on K9 / K10 (k9_update<true>, k10_generate<true>): the flagged records are ALSO written, in
+   * order, to the cache arena at DevState.cache_used; K10's finaliser commits the tile (slot table, bump pointer) */
+  suma_surfel* x_arena;
+  CacheSlot* x_slots;
+  uint32_t x_cap, x_slot;
   /* K9 also records poses_[timestamp_] when K8 did not run as a kernel of its own */
   float* poses_w;
   float* poses_inv_w;
@@ -512,6 +579,11 @@ extern "C" int suma_debug_k9_phases(unsigned long long* host, int reset) {
 #define K9_DEFER 1
 #endif
 #define K9_BUFS (K9_DEFER ? 2 : 1)
+/* XF: the extraction that follows this update (K12, one tile) rides on the stream-out -- the flagged records get a
+ * second stable rank (their place in the tile's cache block) from the same ballots, barrier and look-back words, and are
+ * written to the cache arena next to their place in the map; K12 would copy exactly these records in exactly this
+ * order one launch later (launch + ticket + look-back for 1 byte per surfel: 14 us on every second scan). */
+template <bool XF>
 __global__ void __launch_bounds__(K9_THREADS)
 #if !K9_DEFER
     __attribute__((amdgpu_waves_per_eu(2 * K9_WAVES / 4, 2 * K9_WAVES / 4)))
@@ -520,8 +592,11 @@ __global__ void __launch_bounds__(K9_THREADS)
   __shared__ float4 s_out[K9_BUFS][SUMA_TILE][4]; /* updated records at their uncompacted slot, double buffered */
   __shared__ uint16_t s_slot[K9_BUFS][SUMA_TILE]; /* stable rank -> slot */
   __shared__ uint8_t s_ext[K9_BUFS][SUMA_TILE];   /* slot -> "in the tile that is extracted after this update" */
-  __shared__ uint32_t s_cnt_emit[K9_PER][K9_WAVES], s_cnt_keep[K9_WAVES];
-  __shared__ uint32_t s_tile, s_prefix;
+  __shared__ uint16_t s_xrank[XF ? K9_BUFS : 1][XF ? SUMA_TILE : 1]; /* slot -> rank among the tile's extracted records */
+  __shared__ uint32_t s_cnt_emit[K9_PER][K9_WAVES], s_cnt_keep[K9_WAVES], s_cnt_x[K9_PER][K9_WAVES];
+  __shared__ uint32_t s_tile, s_prefix, s_prefix_x;
+  const uint32_t xbase = XF ? a.ds->cache_used : 0u; /* stable during the update: K10's finaliser moves it */
+  float4* __restrict__ xdst4 = reinterpret_cast<float4*>(a.x_arena);
   const uint32_t S = a.ds->n_surfels;
   const uint32_t ntiles = (S + SUMA_TILE - 1) / SUMA_TILE;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.in);
@@ -530,7 +605,33 @@ __global__ void __launch_bounds__(K9_THREADS)
   uint32_t keep_count = 0; /* thread 0: survivors before the area filter (S') */
   if (a.write_pose && blockIdx.x == 0 && threadIdx.x == 0) write_pose_entry(a.poses_w, a.poses_inv_w, a.pose_idx, a.pose);
   /* the tile whose records wait in LDS for their output offset */
-  uint32_t prev_tile = 0xffffffffu, prev_total = 0, buf = 0;
+  uint32_t prev_tile = 0xffffffffu, prev_total = 0, prev_totalx = 0, buf = 0;
+  /* compacted stream-out of the tile in buffer pb: chunk c = (rank, 16-byte part) */
+  auto stream_out = [&](uint32_t pb, uint32_t tile_id, uint32_t count, uint32_t countx) {
+    const uint32_t prefix = s_prefix, prefix_x = XF ? s_prefix_x : 0u;
+    for (uint32_t c = threadIdx.x; c < 4u * count; c += K9_THREADS) {
+      const uint64_t d = 4ull * prefix + c;
+      if (d < 4ull * a.max_surfels) {
+        const uint32_t slot = s_slot[pb][c >> 2];
+        const float4 v = s_out[pb][slot][c & 3u];
+        store_stream(&dst4[d], v);
+        if (XF) {
+          if (s_ext[pb][slot]) {
+            const uint32_t xr = prefix_x + s_xrank[pb][slot];
+            if (xr < SUMA_EXTRACT_CAPACITY && (uint64_t)xbase + xr < a.x_cap)
+              store_stream(&xdst4[4ull * ((uint64_t)xbase + xr) + (c & 3u)], v);
+          }
+        } else if (a.ex_flags != nullptr && (c & 3u) == 0) {
+          a.ex_flags[d >> 2] = s_ext[pb][slot];
+        }
+      }
+    }
+    if (tile_id == ntiles - 1 && threadIdx.x == 0) {
+      const uint32_t tot = prefix + count;
+      a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
+      if (XF) a.ds->n_ext_update = prefix_x + countx;
+    }
+  };
   PH_BEGIN;
   for (;;) {
     PH(7); /* loop overhead */
@@ -540,7 +641,7 @@ __global__ void __launch_bounds__(K9_THREADS)
     lds_barrier();
     const uint32_t tile = s_tile;
     PH(0); /* ticket: atomic round trip between two barriers */
-    uint32_t total = 0;
+    uint32_t total = 0, totalx = 0;
     if (tile < ntiles) {
       /* lane t handles slots t, K9_THREADS + t, ...: slot order = surfel order = stable order */
       uint32_t idx[K9_PER];
@@ -563,7 +664,8 @@ __global__ void __launch_bounds__(K9_THREADS)
 #pragma unroll
       for (int u = 0; u < K9_PER; ++u) rec[u] = k9_gather(a, pre[u]);
       uint32_t kept = 0;
-      unsigned long long eb[K9_PER];
+      unsigned long long eb[K9_PER], xb[K9_PER];
+      bool xt[K9_PER];
 #pragma unroll
       for (int u = 0; u < K9_PER; ++u) {
         Surfel4 o;
@@ -573,6 +675,8 @@ __global__ void __launch_bounds__(K9_THREADS)
         bool in_tile;
         emit[u] = in_active_area(a, o, &in_tile) && keep;
         const uint32_t slot = (uint32_t)u * K9_THREADS + threadIdx.x;
+        xt[u] = in_tile && emit[u];
+        xb[u] = XF ? __ballot(xt[u]) : 0ull;
         s_ext[buf][slot] = in_tile ? 1 : 0;
         s_out[buf][slot][0] = o.a;
         s_out[buf][slot][1] = o.b;
@@ -585,10 +689,13 @@ __global__ void __launch_bounds__(K9_THREADS)
       if (lane == 0) {
         s_cnt_keep[wave] = kept; /* S' statistics (parity with the reference's TF count) */
 #pragma unroll
-        for (int u = 0; u < K9_PER; ++u) s_cnt_emit[u][wave] = __popcll(eb[u]);
+        for (int u = 0; u < K9_PER; ++u) {
+          s_cnt_emit[u][wave] = __popcll(eb[u]);
+          if (XF) s_cnt_x[u][wave] = __popcll(xb[u]);
+        }
       }
       lds_barrier();
-      uint32_t kc = 0, base = 0;
+      uint32_t kc = 0, base = 0, basex = 0;
       const unsigned long long below = (1ull << lane) - 1ull;
 #pragma unroll
       for (int u = 0; u < K9_PER; ++u) {
@@ -601,13 +708,25 @@ __global__ void __launch_bounds__(K9_THREADS)
         }
         if (emit[u]) s_slot[buf][base + off + __popcll(eb[u] & below)] = (uint16_t)((uint32_t)u * K9_THREADS + threadIdx.x);
         base += tot;
+        if (XF) {
+          uint32_t offx = 0, totx = 0;
+#pragma unroll
+          for (int w = 0; w < K9_WAVES; ++w) {
+            const uint32_t cnt = s_cnt_x[u][w];
+            if (w < wave) offx += cnt;
+            totx += cnt;
+          }
+          if (xt[u]) s_xrank[buf][(uint32_t)u * K9_THREADS + threadIdx.x] = (uint16_t)(basex + offx + __popcll(xb[u] & below));
+          basex += totx;
+        }
       }
 #pragma unroll
       for (int w = 0; w < K9_WAVES; ++w) kc += s_cnt_keep[w];
       total = base;
+      totalx = basex;
       if (threadIdx.x == 0) {
         keep_count += kc;
-        lookback_publish(a.status, a.group, tile, total, a.epoch);
+        lookback_publish(a.status, a.group, tile, total, a.epoch, totalx);
       }
       PH(3); /* ranks (one barrier) + publish */
     }
@@ -616,54 +735,34 @@ __global__ void __launch_bounds__(K9_THREADS)
      * now (one tile's compute later) the words are almost always there */
     if (prev_tile != 0xffffffffu) {
       if (threadIdx.x < 64) {
-        const uint32_t pre = lookback_collect(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
-        if (threadIdx.x == 0) s_prefix = pre;
+        const Pair pre = lookback_collect2<XF>(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
+        if (threadIdx.x == 0) {
+          s_prefix = pre.a;
+          if (XF) s_prefix_x = pre.x;
+        }
       }
       lds_barrier();
       PH(4); /* look-back collect of the previous tile + barrier */
-      const uint32_t prefix = s_prefix, pb = buf ^ 1u;
-      /* compacted stream-out: chunk c = (rank, 16-byte part) */
-      for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
-        const uint64_t d = 4ull * prefix + c;
-        if (d < 4ull * a.max_surfels) {
-          const uint32_t slot = s_slot[pb][c >> 2];
-          store_stream(&dst4[d], s_out[pb][slot][c & 3u]);
-          if (a.ex_flags != nullptr && (c & 3u) == 0) a.ex_flags[d >> 2] = s_ext[pb][slot];
-        }
-      }
-      if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
-        const uint32_t tot = prefix + prev_total;
-        a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
-      }
+      stream_out(buf ^ 1u, prev_tile, prev_total, prev_totalx);
       PH(5); /* stream-out of the previous tile issued */
     }
     if (tile >= ntiles) break;
     prev_tile = tile;
     prev_total = total;
+    prev_totalx = totalx;
 #if K9_DEFER
     buf ^= 1u;
 #else
     /* single buffer: this tile's offset and stream-out right away */
     if (threadIdx.x < 64) {
-      const uint32_t pre = lookback_collect(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
-      if (threadIdx.x == 0) s_prefix = pre;
+      const Pair pre = lookback_collect2<XF>(a.status, a.group, prev_tile, a.epoch, threadIdx.x, &a.ds->overflow);
+      if (threadIdx.x == 0) {
+        s_prefix = pre.a;
+        if (XF) s_prefix_x = pre.x;
+      }
     }
     lds_barrier();
-    {
-      const uint32_t prefix = s_prefix;
-      for (uint32_t c = threadIdx.x; c < 4u * prev_total; c += K9_THREADS) {
-        const uint64_t d = 4ull * prefix + c;
-        if (d < 4ull * a.max_surfels) {
-          const uint32_t slot = s_slot[0][c >> 2];
-          store_stream(&dst4[d], s_out[0][slot][c & 3u]);
-          if (a.ex_flags != nullptr && (c & 3u) == 0) a.ex_flags[d >> 2] = s_ext[0][slot];
-        }
-      }
-      if (prev_tile == ntiles - 1 && threadIdx.x == 0) {
-        const uint32_t tot = prefix + prev_total;
-        a.ds->n_kept_updated = tot < a.max_surfels ? tot : a.max_surfels;
-      }
-    }
+    stream_out(0u, prev_tile, prev_total, prev_totalx);
     prev_tile = 0xffffffffu;
 #endif
   }
@@ -672,7 +771,10 @@ __global__ void __launch_bounds__(K9_THREADS)
     __hip_atomic_fetch_add(&a.ds->n_updated, keep_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (is_finaliser(s_tile, ntiles)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
-    if (threadIdx.x == 0 && ntiles == 0) a.ds->n_kept_updated = 0;
+    if (threadIdx.x == 0 && ntiles == 0) {
+      a.ds->n_kept_updated = 0;
+      if (XF) a.ds->n_ext_update = 0;
+    }
   }
 }
 
@@ -680,16 +782,19 @@ __global__ void __launch_bounds__(K9_THREADS)
  * pixels, in the order of vbo_img_coords_ (x-major, SurfelMap.cpp:88-92).  Appends behind the
  * survivors of K9.  Also exports the K7 winners as a uint32 index map and leaves the z-buffer
  * cleared for the next user. */
+template <bool XF>
 __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
   __shared__ uint32_t s_tile;
-  __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES];
-  __shared__ uint32_t s_prefix;
+  __shared__ uint32_t s_wave_a[TILE_WAVES], s_wave_b[TILE_WAVES], s_wave_x[TILE_WAVES];
+  __shared__ uint32_t s_prefix, s_prefix_x;
   __shared__ uint8_t s_flag[SUMA_TILE];
   __shared__ uint32_t s_rank[SUMA_TILE];
   const int32_t W = a.q.W, H = a.q.H;
   const uint32_t P = (uint32_t)W * (uint32_t)H;
   const uint32_t ntiles = (P + SUMA_TILE - 1) / SUMA_TILE;
   const uint32_t base = a.ds->n_kept_updated;
+  const uint32_t xbase = XF ? a.ds->cache_used : 0u;      /* moved by the finaliser only */
+  const uint32_t xfirst = XF ? a.ds->n_ext_update : 0u;   /* K9's extracted records come first (map order) */
   const float color = pack_rgb(0.0f, 0.0f, 1.0f);
   uint32_t new_count = 0;
   for (;;) {
@@ -747,22 +852,41 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
       if ((threadIdx.x & 63) == 0) s_wave_b[threadIdx.x >> 6] = __popcll(gb);
     }
     /* rank in x-major order: flags -> LDS[q], ranked by the lane whose id is the x-major index */
-    s_flag[q] = emit ? 1 : 0;
+    s_flag[q] = (emit ? 1 : 0) | ((XF && emit && in_tile) ? 2 : 0);
     __syncthreads();
-    BlockRank br = block_rank(s_flag[threadIdx.x] != 0, s_wave_a);
-    s_rank[threadIdx.x] = br.rank;
+    BlockRank br, brx;
+    if (XF) {
+      block_rank2((s_flag[threadIdx.x] & 1) != 0, (s_flag[threadIdx.x] & 2) != 0, s_wave_a, s_wave_x, &br, &brx);
+      s_rank[threadIdx.x] = br.rank | (brx.rank << 16);
+    } else {
+      br = block_rank(s_flag[threadIdx.x] != 0, s_wave_a);
+      brx.rank = brx.total = 0;
+      s_rank[threadIdx.x] = br.rank;
+    }
     if (threadIdx.x == 0)
       for (int w = 0; w < (int)TILE_WAVES; ++w) new_count += s_wave_b[w];
     if (threadIdx.x < 64) {
-      uint32_t pre = lookback_prefix(a.status, a.group, tile, br.total, a.epoch, threadIdx.x, &a.ds->overflow);
-      if (threadIdx.x == 0) s_prefix = pre;
+      if (threadIdx.x == 0) lookback_publish(a.status, a.group, tile, br.total, a.epoch, brx.total);
+      const Pair pre = lookback_collect2<XF>(a.status, a.group, tile, a.epoch, threadIdx.x, &a.ds->overflow);
+      if (threadIdx.x == 0) {
+        s_prefix = pre.a;
+        if (XF) s_prefix_x = pre.x;
+      }
     }
     __syncthreads();
     if (emit) {
-      uint64_t dst = (uint64_t)base + s_prefix + s_rank[q];
+      const uint32_t rk = s_rank[q];
+      uint64_t dst = (uint64_t)base + s_prefix + (XF ? (rk & 0xffffu) : rk);
       if (dst < a.max_surfels) {
         store_surfel(a.out, (uint32_t)dst, s);
-        if (a.ex_flags != nullptr) a.ex_flags[dst] = in_tile ? 1 : 0;
+        if (XF) {
+          if (in_tile) {
+            const uint64_t xr = (uint64_t)xfirst + s_prefix_x + (rk >> 16);
+            if (xr < SUMA_EXTRACT_CAPACITY && (uint64_t)xbase + xr < a.x_cap) store_surfel(a.x_arena, (uint32_t)(xbase + xr), s);
+          }
+        } else if (a.ex_flags != nullptr) {
+          a.ex_flags[dst] = in_tile ? 1 : 0;
+        }
       }
     }
     if (tile == ntiles - 1 && threadIdx.x == 0) {
@@ -774,11 +898,15 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
         atomicOr(&a.ds->overflow, 1u);
       }
       a.ds->n_surfels = (uint32_t)total; /* the compaction target becomes the active map */
+      if (XF) a.ds->n_extracted = xfirst + s_prefix_x + brx.total;
     }
   }
   if (threadIdx.x == 0 && new_count)
     __hip_atomic_fetch_add(&a.ds->n_data, new_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (is_finaliser(s_tile, ntiles)) finalise_tickets(a.ds, a.group_next, a.group_words);
+  if (is_finaliser(s_tile, ntiles)) {
+    finalise_tickets(a.ds, a.group_next, a.group_words);
+    if (XF && threadIdx.x == 0) commit_extraction(a.ds, a.x_slots, a.x_slot, xbase, a.x_cap, a.ds->n_extracted);
+  }
 }
 
 static void set_m4(m4& d, const float* s) {
@@ -813,7 +941,7 @@ K8Out launch_k8_out(suma_ctx* c) {
 /* K7..K11 of SurfelMap::update for the current map (c->surfels[c->cur]); the result lands in the
  * other buffer, which the caller makes current. */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent, int k7_done, const float* ex) {
+                             float cy, float extent, int k7_done, const float* ex, int fused_slot) {
   const uint32_t P = (uint32_t)c->P;
   const double S = (double)c->known_surfels;
   UpdArgs a;
@@ -860,7 +988,12 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.cx = cx;
   a.cy = cy;
   a.extent = extent;
-  a.ex_flags = ex ? c->extract_flags : nullptr;
+  a.ex_flags = (ex && fused_slot < 0) ? c->extract_flags : nullptr;
+  const bool xf = ex && fused_slot >= 0;
+  a.x_arena = xf ? c->cache_arena : nullptr;
+  a.x_slots = c->cache_slots;
+  a.x_cap = c->cache_cap;
+  a.x_slot = xf ? (uint32_t)fused_slot : 0u;
   a.ex_cx = ex ? ex[0] : 0.0f;
   a.ex_cy = ex ? ex[1] : 0.0f;
   a.ex_extent = ex ? ex[2] : 0.0f;
@@ -888,14 +1021,21 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     a.epoch = ++c->epoch;
     a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
     a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
-    k9_update<<<compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P), K9_THREADS, 0, st>>>(a);
+    const uint32_t grid = compact_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
+    if (xf)
+      k9_update<true><<<grid, K9_THREADS, 0, st>>>(a);
+    else
+      k9_update<false><<<grid, K9_THREADS, 0, st>>>(a);
   }
   {
     ProfScope ps(c, "k10_generate_surfels", (80.0 + 12.0) * P + 64.0 * P * 0.5);
     a.epoch = ++c->epoch;
     a.group = c->tile_group + (size_t)(a.epoch & 1u) * c->group_words;
     a.group_next = c->tile_group + (size_t)((a.epoch + 1u) & 1u) * c->group_words;
-    k10_generate<<<compact_grid(c, P), SUMA_TILE, 0, st>>>(a);
+    if (xf)
+      k10_generate<true><<<compact_grid(c, P), SUMA_TILE, 0, st>>>(a);
+    else
+      k10_generate<false><<<compact_grid(c, P), SUMA_TILE, 0, st>>>(a);
   }
   return hipGetLastError();
 }
@@ -1061,21 +1201,7 @@ __global__ void __launch_bounds__(SUMA_TILE) k12_extract(ExtractArgs a) {
   }
   if (is_finaliser(s_tile, ntiles)) {
     finalise_tickets(a.ds, a.group_next, a.group_words);
-    if (threadIdx.x == 0) {
-      uint32_t n = (ntiles == 0) ? 0u : a.ds->n_extracted;
-      if (n > SUMA_EXTRACT_CAPACITY) {
-        n = SUMA_EXTRACT_CAPACITY;
-        atomicOr(&a.ds->overflow, 4u);
-      }
-      if ((uint64_t)base + n > a.arena_cap) {
-        n = a.arena_cap - base;
-        atomicOr(&a.ds->overflow, 2u);
-      }
-      a.slots[a.slot].offset = base;
-      a.slots[a.slot].count = n;
-      a.ds->cache_used = base + n;
-      a.ds->n_extracted = n;
-    }
+    if (threadIdx.x == 0) commit_extraction(a.ds, a.slots, a.slot, base, a.arena_cap, (ntiles == 0) ? 0u : a.ds->n_extracted);
   }
 }
 

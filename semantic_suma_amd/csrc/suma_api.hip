@@ -959,6 +959,19 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     c->extraction.pop_back();
     float cx, cy;
     submap_center(c, idx.first, idx.second, &cx, &cy);
+    const auto account = [&]() {
+      const uint64_t most = (uint64_t)c->known_surfels + 2 * c->P; /* a tile holds at most the whole map ... */
+      c->cache_bound += most < SUMA_EXTRACT_CAPACITY ? most : SUMA_EXTRACT_CAPACITY; /* ... or K12's capacity */
+    };
+    if (c->flagged.valid && c->flagged.fused && c->flagged.i == idx.first && c->flagged.j == idx.second) {
+      /* the update that has just run wrote this tile's records to the arena and committed its slot */
+      c->flagged.valid = false;
+      account();
+      if (partially) break;
+      continue;
+    }
+    if (c->flagged.valid && c->flagged.fused)
+      return fail(c, SUMA_ERR_INVALID, "internal: the update extracted a tile other than the one updateActiveSubmaps asks for");
     uint32_t slot;
     int r = cache_slot_for(c, idx.first, idx.second, &slot);
     if (r) return r;
@@ -969,10 +982,7 @@ static int extract_surfels(suma_ctx* c, bool partially) {
     const int use_flags = (c->flagged.valid && c->flagged.i == idx.first && c->flagged.j == idx.second) ? 1 : 0;
     c->flagged.valid = false;
     CK(launch_extract(c, slot, cx, cy, c->p.submap_extent, use_flags));
-    {
-      const uint64_t most = (uint64_t)c->known_surfels + 2 * c->P; /* a tile holds at most the whole map ... */
-      c->cache_bound += most < SUMA_EXTRACT_CAPACITY ? most : SUMA_EXTRACT_CAPACITY; /* ... or K12's capacity */
-    }
+    account();
     if (partially) break;
   }
   return SUMA_OK;
@@ -987,7 +997,9 @@ static int append_cached(suma_ctx* c, int32_t i, int32_t j) {
 
 /* The tile updateActiveSubmaps -> extractSurfels(partially = true) will extract right after the update at `pose`
  * (SurfelMap.cpp:744-824, 708-742): the same decisions on a copy of the state.  false: none, or not exactly one. */
-static bool peek_extraction(const suma_ctx* c, const float* pose, int32_t* ti, int32_t* tj) {
+static bool peek_extraction(const suma_ctx* c, const float* pose, int32_t* ti, int32_t* tj, bool* appends) {
+  *appends = false;
+  const auto cached = [&](int32_t i, int32_t j) { return c->cache_index.find(std::make_pair(i, j)) != c->cache_index.end(); };
   if (!c->p.partial_extraction || getenv("SUMA_NO_EXTRACT_FLAGS")) return false; /* all pending tiles in one go: no single tile to flag */
   const int32_t dim = c->p.submap_dimension;
   const float ext = c->p.submap_extent;
@@ -1002,11 +1014,13 @@ static bool peek_extraction(const suma_ctx* c, const float* pose, int32_t* ti, i
     last = {oi - dir * dim, oj + dim}; /* the last tile of the pushed row, k = dim */
     have = true;
     oi += dir;
+    for (int32_t k = -dim; k <= dim; ++k) *appends |= cached(oi + dir * dim, oj + k);
   }
   if (fabsf(changey) > factor * ext) {
     const int32_t dir = (changey < 0) ? -1 : 1;
     last = {oi + dim, oj - dir * dim};
     have = true;
+    for (int32_t r0 = -dim; r0 <= dim; ++r0) *appends |= cached(oi + r0, oj + dir + dir * dim);
   }
   if (!have) return false;
   *ti = last.first;
@@ -1082,15 +1096,27 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
   if (c->k8_fused_frame == frame && c->k8_fused_version != frame->version) c->k8_fused_frame = nullptr;
   float ex[3];
   int32_t ti = 0, tj = 0;
-  const bool flag_tile = peek_extraction(c, pose, &ti, &tj);
+  bool appends = false;
+  const bool flag_tile = peek_extraction(c, pose, &ti, &tj, &appends);
+  int fused_slot = -1;
   if (flag_tile) {
     submap_center(c, ti, tj, &ex[0], &ex[1]);
     ex[2] = c->p.submap_extent;
+    /* no cached tile comes back into the map between this update and the extraction (the usual case: the sensor is not
+     * revisiting): the extraction is the update's own stream-out (k9_update<true>, k10_generate<true>).  Anything that
+     * stands in the way -- slot table full, arena to be compacted and still full -- is left to the extraction proper,
+     * which reports it where it always did */
+    if (!appends && !getenv("SUMA_NO_FUSED_EXTRACT") && c->cache_index.size() < c->cache_slots_cap) {
+      uint32_t slot;
+      if (cache_slot_for(c, ti, tj, &slot) == SUMA_OK && cache_compact_if_needed(c, slot) == SUMA_OK) fused_slot = (int)slot;
+    }
   }
   c->flagged.valid = flag_tile;
   c->flagged.i = ti;
   c->flagged.j = tj;
-  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done, flag_tile ? ex : nullptr));
+  c->flagged.fused = fused_slot >= 0;
+  c->flagged.slot = fused_slot >= 0 ? (uint32_t)fused_slot : 0u;
+  CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done, flag_tile ? ex : nullptr, fused_slot));
   c->cur ^= 1;
   c->map_version++;
   int r = update_active_submaps(c, pose);
@@ -1313,6 +1339,24 @@ extern "C" int suma_map_counts(suma_ctx* c, uint32_t* n_updated, uint32_t* n_new
     origin_ij[1] = c->origin_j;
   }
   return SUMA_OK;
+}
+
+extern "C" int suma_map_download_cached_tile(suma_ctx* c, int32_t i, int32_t j, suma_surfel* host, uint32_t capacity,
+                                             uint32_t* n) {
+  if (!c || !n || (capacity && !host)) return SUMA_ERR_INVALID;
+  *n = 0;
+  auto it = c->cache_index.find(std::make_pair(i, j));
+  if (it == c->cache_index.end()) return SUMA_OK;
+  CacheSlot q;
+  CK(hipMemcpyAsync(&q, c->cache_slots + it->second, sizeof(CacheSlot), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  *n = q.count;
+  const uint32_t m = q.count < capacity ? q.count : capacity;
+  if (m) {
+    CK(hipMemcpyAsync(host, c->cache_arena + q.offset, (size_t)m * sizeof(suma_surfel), hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream));
+  }
+  return check_overflow(c);
 }
 
 extern "C" int suma_map_cache_stats(suma_ctx* c, uint32_t* used, uint32_t* capacity, uint32_t* compactions) {

@@ -42,7 +42,8 @@ struct DevState {
   uint32_t reserved0;      /* blocks-done counter of a self-closing objective pass (k_icp.hip) */
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
   uint32_t fault_site;     /* which bounded spin gave up (bit per site; reported with overflow bit 3) */
-  uint32_t pad[5];
+  uint32_t n_ext_update;   /* extraction fused into the update: records K9 sent to the cache arena (K10's come behind) */
+  uint32_t pad[4];
 };
 
 /* one cached submap tile in the device arena */
@@ -198,6 +199,8 @@ struct suma_ctx {
   struct {
     bool valid;                        /* the last update flagged the tile (i, j) */
     int32_t i, j;
+    bool fused;    /* ... and K9 / K10 have already written and committed the tile's cache block (slot below) */
+    uint32_t slot;
   } flagged;
   uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
   unsigned long long* tile_status;     /* look-back status words */
@@ -352,9 +355,10 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
 hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const float* pose_new,
                                       float conf_threshold);
 /* k_update.hip */
-/* ex: optional centre (x, y) + half-width of the submap tile that will be extracted right after this update */
+/* ex: optional centre (x, y) + half-width of the submap tile that will be extracted right after this update;
+ * fused_slot >= 0: the update performs that extraction itself, into this slot of the cache table */
 hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_pose, const suma_frame* f, float cx,
-                             float cy, float extent, int k7_done, const float* ex);
+                             float cy, float extent, int k7_done, const float* ex, int fused_slot);
 hipError_t launch_clear_index_zbuf(suma_ctx* c);
 K8Out launch_k8_out(suma_ctx* c);
 hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uint32_t n);

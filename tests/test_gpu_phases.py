@@ -174,3 +174,39 @@ def test_cache_arena_is_compacted_when_it_runs_full(hip, oracle_lib):
     used, cap, compactions = hp.map.cache_stats()
     assert cap == 900_000 and compactions >= 1, (used, cap, compactions)
     assert used <= cap
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_parked_tiles_are_the_oracles(hip, oracle_lib, fused, monkeypatch):
+    """extractSurfels (SurfelMap.cpp:708-742): every tile that leaves the window is parked with exactly the records, in
+    exactly the order, of the reference's transform feedback.  Usually the extraction rides on the update's own
+    stream-out (k9_update<true> / k10_generate<true>); when a parked tile comes back in the same scan -- second lap of the
+    circle -- it falls back to the K12 launch.  Both routes, every parked tile compared after every extraction."""
+    if fused:
+        monkeypatch.delenv("SUMA_NO_FUSED_EXTRACT", raising=False)
+    else:
+        monkeypatch.setenv("SUMA_NO_FUSED_EXTRACT", "1")
+    W, H = 900, 64
+    p = params_with_size(W, H, submap_extent=4.0, submap_dimension=2)
+    hp, op = hip.SurfelMapping(p), oracle_lib.OraclePipeline(p, threads=16)
+    n = ls.lap_scans() + 40
+    seen, extractions, compared = set(), 0, 0
+    for k in range(n):
+        sc = ls.scan(k, W, H)
+        hp.processScan(*sc, fixed_iterations=6)
+        op.process_scan(*sc, fixed_iterations=6)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k}: pose"
+        count, (ei, ej) = op.ctx.map_last_extraction()
+        if count != extractions:
+            extractions = count
+            seen.add((int(ei), int(ej)))
+            want = op.ctx.map_cache_tile(int(ei), int(ej))
+            got = hp.map.cached_tile(int(ei), int(ej))
+            assert got.shape[0] == want.shape[0], f"scan {k}: tile ({ei},{ej}) holds {got.shape[0]} surfels, oracle {want.shape[0]}"
+            assert got.tobytes() == want.tobytes(), f"scan {k}: parked tile ({ei},{ej}) differs"
+            compared += want.shape[0]
+    assert extractions > 20 and compared > 50_000, (extractions, compared)
+    for (i, j) in seen:  # the tiles as they stand at the end (re-extracted ones hold their latest block)
+        assert hp.map.cached_tile(i, j).tobytes() == op.ctx.map_cache_tile(i, j).tobytes(), f"tile ({i},{j}) at the end"
+    assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes()
+    assert hp.map.cached_tile(1000, 1000).shape[0] == 0
