@@ -429,11 +429,6 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
     for (int q = 0; q < 4; ++q) tk_col[q] = gin->Tk[4 * (threadIdx.x >> 2) + q];
     tk_self = gin->Tk[threadIdx.x];
   }
-  /* closing launch that reports to the host: the counters it forwards (DevState, 64 bytes) are requested now, with
-   * everything else -- read at the end they were a dependent ~1 us round trip of one thread in front of the PCIe writes */
-  DevState ds_fwd;
-  const bool reports = !PIXEL && g.host_out != nullptr && blockIdx.y == 0 && blockIdx.x == 0 && threadIdx.x == 0;
-  if (reports) ds_fwd = *g.ds;
   /* data-frame loads of this lane's first pixel do not depend on the pose */
   const uint32_t pix0 = blockIdx.x * ICP_THREADS + threadIdx.x;
   float4 vd4 = f4(0, 0, 0, 0), nd4 = vd4, sd4 = vd4;
@@ -667,7 +662,9 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
         h->converged = gout->converged;
         h->iteration = gout->iteration;
         h->n_hist = gout->n_hist;
-        h->ds = ds_fwd;
+        /* read here, behind the solve: requested up front with the prologue's loads the 64 bytes made the launch
+         * 1.4 us LONGER (rocprofv3: 9.33 against 7.90 us; profiles/r04_late_experiments.txt) */
+        h->ds = *g.ds;
         __threadfence_system();
         __hip_atomic_store(&h->seq, g.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       }
