@@ -571,3 +571,38 @@ class VertexMap:
         g.fn("glFinish", None)()
         g.check("gen_vertexmap draw")
         return vmap.read(), smap.read()
+
+
+class IndexMap:
+    """SurfelMap::renderIndexmap (SurfelMap.cpp:586-604; framebuffer :100-110, program :140-150, state :507-509) with the
+    reference's gen_indexmap.{vert,frag}: every surfel of the map as a GL_POINT of size 1 at the centre of the data texel
+    it projects to, three colour attachments, DEPTH24_STENCIL8 + GL_LESS -- the nearest front-facing surfel per texel,
+    ties to the surfel drawn first.  Returns the index attachment as uint32 (gl_VertexID + 1; 0 = no surfel)."""
+
+    def __init__(self, params):
+        p = self.p = params
+        self.W, self.H = p.data_width, p.data_height
+        self.prog = Program({"VERTEX_SHADER": "gen_indexmap.vert", "FRAGMENT_SHADER": "gen_indexmap.frag"})
+        self.prog.set(fov_up=abs(float(np.float32(p.data_fov_up))), fov_down=abs(float(np.float32(p.data_fov_down))),
+                      min_depth=float(p.min_depth), max_depth=float(p.max_depth), width=float(self.W), height=float(self.H),
+                      poseBuffer=5)
+        self.fbo = Framebuffer(self.W, self.H)
+
+    def run(self, surfels, poses, pose, inv_pose):
+        g = Context.get()
+        surfels = np.ascontiguousarray(surfels)
+        vbo = Buffer(surfels.view(np.uint8))
+        vao = surfel_vao(vbo)
+        ptex = BufferTexture(np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 4))
+        targets = [RectTexture(self.W, self.H) for _ in range(3)]  # the reference's first attachment is R32F: same raster
+        g.fn("glPointSize", None, f32)(1.0)
+        common_state(self.W, self.H, "LESS")
+        ptex.bind(5)
+        self.fbo.attach(targets)
+        self.prog.set(pose=np.asarray(pose, dtype=np.float32), inv_pose=np.asarray(inv_pose, dtype=np.float32))
+        self.prog.use()
+        clear()
+        draw_points(vao, surfels.shape[0])
+        g.fn("glFinish", None)()
+        g.check("gen_indexmap draw")
+        return targets[0].read()[..., 0].astype(np.uint32), targets[1].read()

@@ -205,3 +205,31 @@ def test_reference_vertexmap_shaders_in_gl(gl, oracle_lib):
         same = np.all(ov.view(np.uint32) == gv.view(np.uint32), axis=-1)
         assert same.mean() >= 0.98
         assert abs(int((ov[..., 3] > 0.5).sum()) - int((gv[..., 3] > 0.5).sum())) <= 0.005 * (ov[..., 3] > 0.5).sum()
+
+
+def test_reference_indexmap_shaders_in_gl(gl, oracle_lib):
+    """SurfelMap::renderIndexmap (K7) through the reference's gen_indexmap.{vert,frag} in llvmpipe against the index map
+    the oracle's update made of the same map from the same pose: size-1 points at texel centres, GL_LESS on 24-bit depth,
+    the earlier surfel on equal depth.  The shader snaps to texel centres itself, so only the driver's atan / asin can
+    move a surfel to the neighbouring texel: >= 97 % of the texels name the same surfel (measured 99.3 % of 57 600)."""
+    p = params_with_size(W)
+    op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
+    for k in range(12):
+        pts, lab, prob, _ = get_scan(k, W, True)
+        op.process_scan(pts, lab, prob, fixed_iterations=10)
+    ctx = op.ctx
+    before, ts = ctx.map_surfels().copy(), ctx.map_timestamp()
+    pts, lab, prob, _ = get_scan(12, W, True)
+    op.process_scan(pts, lab, prob, fixed_iterations=10)
+    want = ctx.map_index_map()  # K7 of that update: the map as it was, from the pose the update was given
+    pose = op.pose().astype(np.float32)
+    R, t = pose[:3, :3], pose[:3, 3]
+    inv = np.eye(4, dtype=np.float32)  # the rigid inverse in float, as the HIP path and the oracle form it (DESIGN 2)
+    inv[:3, :3] = R.T
+    inv[:3, 3] = -(R.T @ t)
+    got, gv = gl.IndexMap(p).run(before, ctx.map_poses(ts + 1).reshape(-1, 16), pose, inv)
+    assert want.shape == got.shape and (want > 0).sum() > 20000
+    same = want == got
+    assert same.mean() >= 0.97, same.mean()
+    assert abs(int((want > 0).sum()) - int((got > 0).sum())) <= 0.01 * (want > 0).sum()
+    assert got.max() <= before.shape[0]
