@@ -606,3 +606,48 @@ class IndexMap:
         g.fn("glFinish", None)()
         g.check("gen_indexmap draw")
         return targets[0].read()[..., 0].astype(np.uint32), targets[1].read()
+
+
+class NormalsLabels:
+    """Preprocessing::process, passes 2 and 3 (Preprocessing.cpp:238-327; programs :45-53, sampler :68-70) with the
+    reference's empty.vert + quad.geom + gen_normalmap.frag / floodfill.frag: one GL_POINT expanded to a full-screen quad,
+    interpolated texCoords, NEAREST + CLAMP_TO_BORDER sampler objects on both units, no depth test.  Input: the vertex
+    map and the raw semantic map of pass 1.  Returns (normal map, eroded labels, refined labels)."""
+
+    def __init__(self, params):
+        self.W, self.H = params.data_width, params.data_height
+        stages = lambda frag: {"VERTEX_SHADER": "empty.vert", "GEOMETRY_SHADER": "quad.geom", "FRAGMENT_SHADER": frag}
+        self.normal = Program(stages("gen_normalmap.frag"))
+        self.flood = Program(stages("floodfill.frag"))
+        for prog in (self.normal, self.flood):
+            prog.set(vertex_map=0, semantic_map=1)  # the only uniforms the reference sets (Preprocessing.cpp:113-116)
+        self.fbo = Framebuffer(self.W, self.H)
+        self.sampler = Sampler(linear=False)
+        self.vao = gen("VertexArrays")  # vao_no_points_
+
+    def _pass(self, prog, vmap_tex, sem_tex, n_out):
+        g = Context.get()
+        outs = [RectTexture(self.W, self.H) for _ in range(n_out)]
+        g.fn("glDisable", None, u32)(GL["DEPTH_TEST"])
+        g.fn("glClearColor", None, f32, f32, f32, f32)(0, 0, 0, 0)
+        g.fn("glViewport", None, i32, i32, i32, i32)(0, 0, self.W, self.H)
+        self.fbo.attach(outs)
+        vmap_tex.bind(0)
+        sem_tex.bind(1)
+        self.sampler.bind(0)
+        self.sampler.bind(1)
+        prog.use()
+        clear()
+        draw_points(self.vao, 1)
+        g.fn("glFinish", None)()
+        g.fn("glBindSampler", None, u32, u32)(0, 0)
+        g.fn("glBindSampler", None, u32, u32)(1, 0)
+        g.check("full-screen pass")
+        return outs
+
+    def run(self, vmap, smap):
+        v = RectTexture(self.W, self.H, vmap)
+        s = RectTexture(self.W, self.H, smap)
+        nmap, eroded = self._pass(self.normal, v, s, 2)
+        (refined,) = self._pass(self.flood, v, eroded, 1)
+        return nmap.read(), eroded.read(), refined.read()

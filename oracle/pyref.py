@@ -206,6 +206,14 @@ class Ref:
             self.L.ref_pass_bilateral(W, H, _p(temp))
             if p.use_filtered_vertexmap:
                 vmap = temp  # Preprocessing.cpp:234
+        nmap, _, refined = self.normals_and_labels(vmap, smap)
+        return vmap, nmap, refined
+
+    def normals_and_labels(self, vmap, smap):
+        """passes 2 and 3 of Preprocessing::process on given maps: (normal map, eroded labels, refined labels)"""
+        W, H = self.W, self.H
+        vmap = np.ascontiguousarray(vmap, dtype=np.float32)
+        smap = np.ascontiguousarray(smap, dtype=np.float32)
         # pass 2 (Preprocessing.cpp:238-279): sampler NEAREST + CLAMP_TO_BORDER (:68-70)
         self._tex("gen_normalmap", "vertex_map", vmap, NEAREST)
         self._tex("gen_normalmap", "semantic_map", smap, NEAREST)
@@ -217,7 +225,7 @@ class Ref:
         self._tex("floodfill", "semantic_map", eroded, NEAREST)
         refined = np.zeros((H, W, 4), dtype=np.float32)
         self.L.ref_pass_floodfill(W, H, _p(refined))
-        return vmap, nmap, refined
+        return nmap, eroded, refined
 
     # -- K6  Frame2Model::jacobianProducts (Frame2Model.cpp:136-261; uniforms :65-110,194-195)
     def jacobians(self, cur, model, pose, iteration, entries_per_kernel=64, gates=None):
