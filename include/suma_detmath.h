@@ -68,12 +68,17 @@ SUMA_HD float sdm_floor(float x) {
   return (t > x) ? (t - 1.0f) : t;
 }
 
-/* round half away from zero (C roundf); the pipeline only feeds near-integers */
+/* GLSL round(): "the fraction 0.5 will round in a direction chosen by the implementation".  Ties DO occur on this path
+ * -- pack(vec3(0.3)) and pack(vec3(0, 0.7, 0)) of color.glsl are 76.5 and 178.5 -- and the implementations that exist
+ * round them to EVEN (the hardware's round-to-nearest instruction; Mesa llvmpipe does, measured by
+ * tests/test_gl_reference.py through the reference's own update_surfels.vert), not away from zero as C's roundf does
+ * (rounds 1-3 of this repository).  Exact for |x| < 2^23, larger values are integral already. */
 SUMA_HD float sdm_round(float x) {
   if (!(sdm_abs(x) < 8388608.0f)) return x;
   float a = sdm_abs(x);
-  float t = (float)(int32_t)(a + 0.5f);
-  if (t - a > 0.5f) t = t - 1.0f; /* guards the a+0.5 rounding case */
+  float t = (float)(int32_t)a; /* truncation; a - t is exact */
+  float f = a - t;
+  if (f > 0.5f || (f == 0.5f && (((int32_t)t) & 1))) t = t + 1.0f;
   return (x < 0.0f) ? -t : t;
 }
 

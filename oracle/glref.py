@@ -651,3 +651,92 @@ class NormalsLabels:
         nmap, eroded = self._pass(self.normal, v, s, 2)
         (refined,) = self._pass(self.flood, v, eroded, 1)
         return nmap.read(), eroded.read(), refined.read()
+
+
+class SurfelUpdate:
+    """SurfelMap::updateSurfels, first draw (K9; SurfelMap.cpp:621-644, program :152-157, uniforms :399-438, state
+    :507-545) with the reference's update_surfels.{vert,geom,frag}: every surfel of the map as a GL_POINT, TRANSFORM
+    FEEDBACK of the five interleaved varyings (the 64-byte record) in primitive order -- the geometry shader drops the
+    surfels the update removes -- while the surviving points are rasterised into the integration mask.  The map's sampler
+    object (MIN NEAREST / MAG LINEAR / CLAMP_TO_BORDER, :168-170) sits on units 0-6."""
+
+    VARYINGS = ["sfl_position_radius", "sfl_normal_confidence", "sfl_timestamp", "sfl_color_weight_count", "sfl_semantic_map"]
+
+    def __init__(self, params, tag_sources=False):
+        """tag_sources: the geometry shader (a pass-through of the vertex stage's record) gets ONE more output, the index
+        of the input primitive, captured as a sixth feedback word group -- test instrumentation that lets two runs be
+        aligned surfel by surfel when a handful of borderline surfels survive in one and not in the other; the vertex
+        shader, where the update is decided and computed, stays the reference's text"""
+        self.W, self.H = params.data_width, params.data_height
+        self.tagged = bool(tag_sources)
+        geom = shader_source("update_surfels.geom")
+        if tag_sources:
+            assert "out vec4 sfl_semantic_map;" in geom and "EmitVertex();" in geom
+            geom = geom.replace("out vec4 sfl_semantic_map;", "out vec4 sfl_semantic_map;\nout float sfl_source;", 1)
+            geom = geom.replace("EmitVertex();", "sfl_source = float(gl_PrimitiveIDIn);\n    EmitVertex();", 1)
+        self.prog = Program({"VERTEX_SHADER": shader_source("update_surfels.vert"), "GEOMETRY_SHADER": geom,
+                             "FRAGMENT_SHADER": shader_source("update_surfels.frag")},
+                            tf_varyings=self.VARYINGS + (["sfl_source"] if tag_sources else []), from_reference=False)
+        self.prog.set(vertex_map=0, normal_map=1, radiusConfidence_map=2, index_map=3, poseBuffer=5, semantic_map_in=6)
+        self.fbo = Framebuffer(self.W, self.H)
+        g = Context.get()
+        self.sampler = gen("Samplers")
+        sp = g.fn("glSamplerParameteri", None, u32, u32, i32)
+        for pname, val in (("TEXTURE_MIN_FILTER", "NEAREST"), ("TEXTURE_MAG_FILTER", "LINEAR"),
+                           ("TEXTURE_WRAP_S", "CLAMP_TO_BORDER"), ("TEXTURE_WRAP_T", "CLAMP_TO_BORDER")):
+            sp(self.sampler, GL[pname], GL[val])
+
+    def run(self, uniforms, surfels, poses, frame, radconf, index_map_float):
+        """uniforms: [(name, value, kind)] as oracle/pyref.py update_uniforms() lists them.  Returns (the records
+        transform feedback wrote, in order; the integration mask (H, W) of the red channel)."""
+        g = Context.get()
+        W, H = self.W, self.H
+        kw = {}
+        for name, value, kind in uniforms:
+            kw[name] = int(value) if kind == "i" else (np.asarray(value, dtype=np.float32) if kind in "mv" else float(np.float32(value)))
+        self.prog.set(**kw)
+        surfels = np.ascontiguousarray(surfels)
+        n = surfels.shape[0]
+        vao = surfel_vao(Buffer(surfels.view(np.uint8)))
+        idx4 = np.zeros((H, W, 4), dtype=np.float32)
+        idx4[..., 0] = index_map_float  # the reference's texture is R32F: texture().x is all the shader reads
+        tex = [RectTexture(W, H, frame[0]), RectTexture(W, H, frame[1]), RectTexture(W, H, radconf), RectTexture(W, H, idx4)]
+        sem = RectTexture(W, H, frame[2])
+        ptex = BufferTexture(np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 4))
+        mask = RectTexture(W, H)  # created BEFORE the units are populated: creating a texture binds it to the active unit
+        for unit, t in enumerate(tex):
+            t.bind(unit)
+        ptex.bind(5)
+        sem.bind(6)
+        for unit in range(7):
+            g.fn("glBindSampler", None, u32, u32)(unit, self.sampler)
+        g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + 7)
+        g.fn("glPointSize", None, f32)(1.0)
+        common_state(W, H, "LESS")
+        self.fbo.attach([mask])
+        words = 17 if self.tagged else 16
+        out = Buffer(nbytes=max(n, 1) * 4 * words)
+        g.fn("glBindBufferBase", None, u32, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, out.id)
+        q = gen("Queries")
+        self.prog.use()
+        clear()
+        g.fn("glBeginQuery", None, u32, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"], q)
+        g.fn("glBeginTransformFeedback", None, u32)(GL["POINTS"])
+        draw_points(vao, n)
+        g.fn("glEndTransformFeedback", None)()
+        g.fn("glEndQuery", None, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"])
+        g.fn("glFinish", None)()
+        written = u32(0)
+        g.fn("glGetQueryObjectuiv", None, u32, u32, C.POINTER(u32))(q, GL["QUERY_RESULT"], C.byref(written))
+        for unit in range(7):
+            g.fn("glBindSampler", None, u32, u32)(unit, 0)
+        g.check("update_surfels draw")
+        g.fn("glBindBuffer", None, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], out.id)
+        rec = np.empty(written.value * words, dtype=np.float32)
+        if written.value:
+            g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, rec.nbytes,
+                                                                               rec.ctypes.data)
+        rec = rec.reshape(-1, words)
+        if self.tagged:
+            return np.ascontiguousarray(rec[:, :16]), mask.read()[..., 0], rec[:, 16].astype(np.uint32)
+        return rec, mask.read()[..., 0]

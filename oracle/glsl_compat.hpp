@@ -361,8 +361,9 @@ inline float sqrt(float x) { return __builtin_sqrtf(x); }
 inline float abs(float x) { return __builtin_fabsf(x); }
 inline float floor(float x) { return __builtin_floorf(x); }
 inline float fract(float x) { return x - __builtin_floorf(x); }
-/* round(): GLSL leaves the direction for x.5 to the implementation; half away from zero here */
-inline float round(float x) { return __builtin_roundf(x); }
+/* round(): GLSL leaves the direction for x.5 to the implementation; to even, as the GL implementations do (llvmpipe:
+ * measured, tests/test_gl_reference.py) -- nearbyint in the default rounding mode */
+inline float round(float x) { return __builtin_rintf(x); }
 inline float min(float a, float b) { return (b < a) ? b : a; }                 /* GLSL: y < x ? y : x */
 inline float max(float a, float b) { return (a < b) ? b : a; }                 /* GLSL: x < y ? y : x */
 inline float clamp(float x, float lo, float hi) { return min(max(x, lo), hi); } /* GLSL definition */

@@ -60,6 +60,8 @@ def lib(variant=""):
     L.ref_draw_jacobians.argtypes = [i32, i32, i32, vp, vp]
     L.ref_render_quads.argtypes = [vp, u32, vp, vp, vp, vp]
     L.ref_draw_indexmap.argtypes = [vp, u32, i32, i32, vp]
+    L.ref_set_update_sources.argtypes = [vp]
+    L.ref_set_update_sources.restype = None
     L.ref_draw_update.restype = u32
     L.ref_draw_update.argtypes = [vp, u32, i32, i32, vp, u32, vp]
     L.ref_draw_generate.restype = u32
@@ -314,33 +316,37 @@ class Ref:
         return out
 
     # -- K9  SurfelMap::updateSurfels, first draw (SurfelMap.cpp:621-644; uniforms :399-438)
-    def update(self, surfels, poses, pose, timestamp, frame, radconf, index_map_float):
+    def update_uniforms(self, pose, timestamp):
+        """the uniforms of update_program_ as SurfelMap.cpp:399-438 and :626-628 set them: [(name, value, kind)]"""
+        p = self.p
+        up, down = p.data_fov_up, p.data_fov_down
+        return [
+            ("fov_up", abs(np.float32(up)), "f"), ("fov_down", abs(np.float32(down)), "f"),
+            ("min_depth", p.min_depth, "f"), ("max_depth", p.max_depth, "f"),
+            ("width", self.W, "f"), ("height", self.H, "f"),
+            ("pixel_size", self.pixel_size, "f"),
+            ("distance_thresh", p.map_max_distance, "f"),
+            ("angle_thresh", _sinf(np.float32(np.float32(math.pi) / np.float32(180.0)) * np.float32(p.map_max_angle)), "f"),
+            ("confidence_mode", p.confidence_mode, "i"), ("unstable_age", p.unstable_age, "i"),
+            ("p_stable", p.p_stable, "f"), ("p_unstable", self.p_unstable, "f"), ("p_prior", p.p_prior, "f"),
+            ("log_prior", self.log_prior, "f"), ("log_unstable", self.log_unstable, "f"),
+            ("sigma_angle", p.sigma_angle, "f"), ("sigma_distance", p.sigma_distance, "f"),
+            ("confidence_threshold", p.confidence_threshold, "f"),
+            ("min_radius", 0.0, "f"),  # SurfelMap.cpp:422: the update program keeps 0
+            ("max_weight", p.max_weight, "f"),
+            ("weighting_scheme", p.weighting_scheme, "i"), ("averaging_scheme", p.averaging_scheme, "i"),
+            ("update_always", p.update_always, "i"), ("active_timestamps", p.active_timestamps, "i"),
+            ("use_stability", p.use_stability, "i"),
+            ("pose", pose, "m"), ("inv_pose", rigid_inverse_f32(pose), "m"), ("timestamp", timestamp, "i"),
+        ]
+
+    def update(self, surfels, poses, pose, timestamp, frame, radconf, index_map_float, sources=False):
+        """sources=True: also returns, per output record, the index of the input surfel it came from"""
         p = self.p
         prog = "update_surfels"
-        self._proj_uniforms(prog)
-        self._u(prog, "pixel_size", self.pixel_size)
-        self._u(prog, "distance_thresh", p.map_max_distance)
-        self._u(prog, "angle_thresh", _sinf(np.float32(np.float32(math.pi) / np.float32(180.0)) * np.float32(p.map_max_angle)))
-        self._u(prog, "confidence_mode", p.confidence_mode, "i")
-        self._u(prog, "unstable_age", p.unstable_age, "i")
-        self._u(prog, "p_stable", p.p_stable)
-        self._u(prog, "p_unstable", self.p_unstable)
-        self._u(prog, "p_prior", p.p_prior)
-        self._u(prog, "log_prior", self.log_prior)
-        self._u(prog, "log_unstable", self.log_unstable)
-        self._u(prog, "sigma_angle", p.sigma_angle)
-        self._u(prog, "sigma_distance", p.sigma_distance)
-        self._u(prog, "confidence_threshold", p.confidence_threshold)
-        self._u(prog, "min_radius", 0.0)  # SurfelMap.cpp:422: the update program keeps 0
-        self._u(prog, "max_weight", p.max_weight)
-        self._u(prog, "weighting_scheme", p.weighting_scheme, "i")
-        self._u(prog, "averaging_scheme", p.averaging_scheme, "i")
-        self._u(prog, "update_always", p.update_always, "i")
-        self._u(prog, "active_timestamps", p.active_timestamps, "i")
-        self._u(prog, "use_stability", p.use_stability, "i")
-        self._u(prog, "pose", pose, "m")
-        self._u(prog, "inv_pose", rigid_inverse_f32(pose), "m")
-        self._u(prog, "timestamp", timestamp, "i")
+        optional = ("min_depth", "max_depth", "width", "height")
+        for name, value, kind in self.update_uniforms(pose, timestamp):
+            self._u(prog, name, value, kind, required=name not in optional)
         self._buf(prog, "poseBuffer", poses)
         self._tex(prog, "vertex_map", frame[0], LINEAR)
         self._tex(prog, "normal_map", frame[1], LINEAR)
@@ -351,7 +357,12 @@ class Ref:
         cap = int(p.max_surfels)
         out = np.zeros(max(surfels.shape[0], 1), dtype=SURFEL_DTYPE)
         mask = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        src = np.zeros(out.shape[0], dtype=np.uint32)
+        if sources:
+            self.L.ref_set_update_sources(_p(src))
         n = self.L.ref_draw_update(_p(surfels), surfels.shape[0], self.W, self.H, _p(out), min(cap, out.shape[0]), _p(mask))
+        if sources:
+            return out[:n].copy(), mask, src[:n].copy()
         return out[:n].copy(), mask
 
     # -- K10  SurfelMap::updateSurfels, second draw (SurfelMap.cpp:646-664; uniforms :360-376)

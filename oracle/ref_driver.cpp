@@ -432,6 +432,10 @@ static void k9_emit() {
   FS::shader_main();
   store4(g_mask4, pix, FS::color);
 }
+/* optional: src[k] = index of the input surfel that became output record k of the next ref_draw_update (transform
+ * feedback closes up the dropped primitives; tests/test_gl_reference.py aligns two runs by it) */
+static uint32_t* g_update_src = nullptr;
+extern "C" void ref_set_update_sources(uint32_t* src) { g_update_src = src; }
 extern "C" uint32_t ref_draw_update(const suma_surfel* surfels, uint32_t n, int W, int H, suma_surfel* out, uint32_t cap,
                                     float* integrated4) {
   namespace VS = s_update_surfels_vert;
@@ -455,9 +459,12 @@ extern "C" uint32_t ref_draw_update(const suma_surfel* surfels, uint32_t n, int 
     VS::shader_main();
     VS::export_vs_out(GS::gs_in[0]);
     GS::gl_in[0].gl_Position = VS::gl_Position;
+    const uint32_t n0 = g_tf_n;
     GS::shader_main();
+    if (g_update_src && g_tf_n > n0 && n0 < cap) g_update_src[n0] = i;
   }
   GS::emit_cb = nullptr;
+  g_update_src = nullptr;
   free(g_mask_depth);
   return g_tf_n < cap ? g_tf_n : cap;
 }

@@ -58,6 +58,10 @@ def test_atan2_quadrants_and_floor_round(shim):
     assert np.array_equal(run1(shim, "t_floor", v), np.floor(v))
     near = np.round(rng.uniform(0, 255, 1000)).astype(np.float32) + rng.uniform(-0.2, 0.2, 1000).astype(np.float32)
     assert np.array_equal(run1(shim, "t_round", near), np.round(near))
+    # GLSL round() at .5: to even, as the GL implementations do (76.5 and 178.5 are pack()'s ties, color.glsl:34-36)
+    ties = np.array([0.5, 1.5, 2.5, 76.5, 77.5, 178.5, 179.5, -0.5, -1.5, -2.5, 8388607.5, 0.49999997, 0.50000006], dtype=np.float32)
+    assert np.array_equal(run1(shim, "t_round", ties), np.round(ties))
+    assert run1(shim, "t_round", np.array([76.5, 178.5], np.float32)).tolist() == [76.0, 178.0]
 
 
 def test_double_sincos(shim):
