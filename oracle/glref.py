@@ -740,3 +740,206 @@ class SurfelUpdate:
         if self.tagged:
             return np.ascontiguousarray(rec[:, :16]), mask.read()[..., 0], rec[:, 16].astype(np.uint32)
         return rec, mask.read()[..., 0]
+
+
+class SurfelGenerate:
+    """SurfelMap::updateSurfels, second draw (K10; SurfelMap.cpp:646-664, program :57-66, uniforms :360-376) with the
+    reference's gen_surfels.{vert,geom,frag}: one GL_POINT per data texel in the x-major order of vbo_img_coords_
+    (:84-93), GL_RASTERIZER_DISCARD, transform feedback of the new surfels.  Sampler objects as in SurfelUpdate."""
+
+    def __init__(self, params):
+        self.W, self.H = params.data_width, params.data_height
+        # no fragment stage: the draw runs under GL_RASTERIZER_DISCARD, and Mesa's compiler rejects gen_surfels.frag (an
+        # integer fragment input without `flat`, which the reference's NVIDIA compiler lets pass)
+        self.prog = Program({"VERTEX_SHADER": "gen_surfels.vert", "GEOMETRY_SHADER": "gen_surfels.geom"},
+                            tf_varyings=SurfelUpdate.VARYINGS)
+        self.prog.set(vertex_map=0, normal_map=1, radiusConfidence_map=2, measurementIntegrated_map=4, semantic_map=6,
+                      model_semantic_map=9, prior_map=8)
+        g = Context.get()
+        self.sampler = gen("Samplers")
+        sp = g.fn("glSamplerParameteri", None, u32, u32, i32)
+        for pname, val in (("TEXTURE_MIN_FILTER", "NEAREST"), ("TEXTURE_MAG_FILTER", "LINEAR"),
+                           ("TEXTURE_WRAP_S", "CLAMP_TO_BORDER"), ("TEXTURE_WRAP_T", "CLAMP_TO_BORDER")):
+            sp(self.sampler, GL[pname], GL[val])
+
+    def run(self, uniforms, frame, radconf, integrated4):
+        g = Context.get()
+        W, H = self.W, self.H
+        kw = {}
+        for name, value, kind in uniforms:
+            kw[name] = int(value) if kind == "i" else (np.asarray(value, dtype=np.float32) if kind in "mv" else float(np.float32(value)))
+        self.prog.set(**kw)
+        xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="ij")
+        coords = np.stack([xs + np.float32(0.5), ys + np.float32(0.5)], axis=-1).reshape(-1, 2)  # x-major, SurfelMap.cpp:87-91
+        vbo = Buffer(np.ascontiguousarray(coords))
+        vao = gen("VertexArrays")
+        g.fn("glBindVertexArray", None, u32)(vao)
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], vbo.id)
+        g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)(0, 2, GL["FLOAT"], 0, 8, 0)
+        g.fn("glEnableVertexAttribArray", None, u32)(0)
+        tex = {0: RectTexture(W, H, frame[0]), 1: RectTexture(W, H, frame[1]), 2: RectTexture(W, H, radconf),
+               4: RectTexture(W, H, integrated4), 6: RectTexture(W, H, frame[2])}
+        for unit, t in tex.items():
+            t.bind(unit)
+        for unit in range(7):
+            g.fn("glBindSampler", None, u32, u32)(unit, self.sampler)
+        g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + 7)
+        n = W * H
+        out = Buffer(nbytes=n * 64)
+        g.fn("glBindBufferBase", None, u32, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, out.id)
+        q = gen("Queries")
+        self.prog.use()
+        g.fn("glDisable", None, u32)(GL["DEPTH_TEST"])
+        g.fn("glEnable", None, u32)(GL["RASTERIZER_DISCARD"])
+        g.fn("glBeginQuery", None, u32, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"], q)
+        g.fn("glBeginTransformFeedback", None, u32)(GL["POINTS"])
+        draw_points(vao, n)
+        g.fn("glEndTransformFeedback", None)()
+        g.fn("glEndQuery", None, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"])
+        g.fn("glDisable", None, u32)(GL["RASTERIZER_DISCARD"])
+        g.fn("glFinish", None)()
+        written = u32(0)
+        g.fn("glGetQueryObjectuiv", None, u32, u32, C.POINTER(u32))(q, GL["QUERY_RESULT"], C.byref(written))
+        for unit in range(7):
+            g.fn("glBindSampler", None, u32, u32)(unit, 0)
+        g.check("gen_surfels draw")
+        g.fn("glBindBuffer", None, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], out.id)
+        rec = np.empty(written.value * 16, dtype=np.float32)
+        if written.value:
+            g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, rec.nbytes,
+                                                                               rec.ctypes.data)
+        return rec.reshape(-1, 16)
+
+
+class SurfelFilter:
+    """SurfelMap::copySurfels (K11, copy_surfels.vert + copy_surfels.geom, SurfelMap.cpp:160-166, 667-698) and
+    SurfelMap::extractSurfels (K12, extract_surfels.vert + copy_surfels.geom, :280-286, 708-742): the surfel buffer as
+    GL_POINTS, GL_RASTERIZER_DISCARD, transform feedback of the records the vertex stage marks valid.  One feedback
+    object spans several draws (copySurfels appends the new surfels behind the updated ones)."""
+
+    def __init__(self, vertex_shader):
+        self.prog = Program({"VERTEX_SHADER": vertex_shader, "GEOMETRY_SHADER": "copy_surfels.geom",
+                             "FRAGMENT_SHADER": "empty.frag"}, tf_varyings=SurfelUpdate.VARYINGS)
+        self.prog.set(poseBuffer=5)
+
+    def run(self, buffers, poses, center, extent):
+        g = Context.get()
+        self.prog.set(submap_center=np.asarray(center, dtype=np.float32), submap_extent=float(np.float32(extent)))
+        ptex = BufferTexture(np.ascontiguousarray(poses, dtype=np.float32).reshape(-1, 4))
+        total = sum(b.shape[0] for b in buffers)
+        out = Buffer(nbytes=max(total, 1) * 64)
+        vaos = [(surfel_vao(Buffer(np.ascontiguousarray(b).view(np.uint8))), b.shape[0]) for b in buffers]
+        ptex.bind(5)
+        g.fn("glBindBufferBase", None, u32, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, out.id)
+        q = gen("Queries")
+        self.prog.use()
+        g.fn("glEnable", None, u32)(GL["RASTERIZER_DISCARD"])
+        g.fn("glBeginQuery", None, u32, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"], q)
+        g.fn("glBeginTransformFeedback", None, u32)(GL["POINTS"])
+        for vao, n in vaos:
+            if n:
+                draw_points(vao, n)
+        g.fn("glEndTransformFeedback", None)()
+        g.fn("glEndQuery", None, u32)(GL["TRANSFORM_FEEDBACK_PRIMITIVES_WRITTEN"])
+        g.fn("glDisable", None, u32)(GL["RASTERIZER_DISCARD"])
+        g.fn("glFinish", None)()
+        written = u32(0)
+        g.fn("glGetQueryObjectuiv", None, u32, u32, C.POINTER(u32))(q, GL["QUERY_RESULT"], C.byref(written))
+        g.check("surfel filter draw")
+        g.fn("glBindBuffer", None, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], out.id)
+        rec = np.empty(written.value * 16, dtype=np.float32)
+        if written.value:
+            g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, rec.nbytes,
+                                                                               rec.ctypes.data)
+        return rec.reshape(-1, 16)
+
+
+def _map_sampler():
+    """the map's sampler object, SurfelMap.cpp:168-170: MIN NEAREST / MAG LINEAR / CLAMP_TO_BORDER"""
+    g = Context.get()
+    s = gen("Samplers")
+    sp = g.fn("glSamplerParameteri", None, u32, u32, i32)
+    for pname, val in (("TEXTURE_MIN_FILTER", "NEAREST"), ("TEXTURE_MAG_FILTER", "LINEAR"),
+                       ("TEXTURE_WRAP_S", "CLAMP_TO_BORDER"), ("TEXTURE_WRAP_T", "CLAMP_TO_BORDER")):
+        sp(s, GL[pname], GL[val])
+    return s
+
+
+class RadiusConfidence:
+    """SurfelMap::generateDataSurfels (K8; SurfelMap.cpp:606-619, framebuffer :116-126, uniforms :380-397) with the
+    reference's init_radiusConf.{vert,frag}: one GL_POINT per data texel at its centre, two colour attachments written
+    (centred vertex, radius / confidence), depth test LESS against a cleared buffer, the map's sampler on units 0 / 1."""
+
+    def __init__(self, params):
+        self.W, self.H = params.data_width, params.data_height
+        self.prog = Program({"VERTEX_SHADER": "init_radiusConf.vert", "FRAGMENT_SHADER": "init_radiusConf.frag"})
+        self.prog.set(vertex_map=0, normal_map=1)
+        self.fbo = Framebuffer(self.W, self.H)
+        self.sampler = _map_sampler()
+
+    def run(self, uniforms, vmap, nmap):
+        g = Context.get()
+        W, H = self.W, self.H
+        self.prog.set(**uniforms)
+        xs, ys = np.meshgrid(np.arange(W, dtype=np.float32), np.arange(H, dtype=np.float32), indexing="ij")
+        coords = np.stack([xs + np.float32(0.5), ys + np.float32(0.5)], axis=-1).reshape(-1, 2)
+        vbo = Buffer(np.ascontiguousarray(coords))
+        vao = gen("VertexArrays")
+        g.fn("glBindVertexArray", None, u32)(vao)
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], vbo.id)
+        g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)(0, 2, GL["FLOAT"], 0, 8, 0)
+        g.fn("glEnableVertexAttribArray", None, u32)(0)
+        outs = [RectTexture(W, H), RectTexture(W, H)]
+        tv, tn = RectTexture(W, H, vmap), RectTexture(W, H, nmap)
+        tv.bind(0)
+        tn.bind(1)
+        for unit in (0, 1):
+            g.fn("glBindSampler", None, u32, u32)(unit, self.sampler)
+        g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + 7)
+        g.fn("glPointSize", None, f32)(1.0)
+        common_state(W, H, "LESS")
+        self.fbo.attach(outs)
+        self.prog.use()
+        clear()
+        draw_points(vao, W * H)
+        g.fn("glFinish", None)()
+        for unit in (0, 1):
+            g.fn("glBindSampler", None, u32, u32)(unit, 0)
+        g.check("init_radiusConf draw")
+        return outs[1].read(), outs[0].read()
+
+
+class Compose:
+    """the compose pass of SurfelMap::render (K5; SurfelMap.cpp:249-263 program, :911-961 draw) with the reference's
+    empty.vert + quad.geom + render_compose.frag: old / new vertex, normal and semantic maps on units 0-4 and 6 under the
+    map's sampler (MAG LINEAR at a 1:1 mapping), three colour attachments."""
+
+    def __init__(self, params):
+        self.W, self.H = params.model_width, params.model_height
+        self.prog = Program({"VERTEX_SHADER": "empty.vert", "GEOMETRY_SHADER": "quad.geom", "FRAGMENT_SHADER": "render_compose.frag"})
+        self.prog.set(old_vertexmap=0, old_normalmap=1, new_vertexmap=2, new_normalmap=3, poseBuffer=5, new_semanticmap=4,
+                      old_semanticmap=6, max_distance=float(np.float32(params.max_loop_closure_distance)))
+        self.fbo = Framebuffer(self.W, self.H)
+        self.sampler = _map_sampler()
+        self.vao = gen("VertexArrays")
+
+    def run(self, old, new):
+        g = Context.get()
+        W, H = self.W, self.H
+        outs = [RectTexture(W, H) for _ in range(3)]
+        units = {0: old[0], 1: old[1], 2: new[0], 3: new[1], 4: new[2], 6: old[2]}
+        tex = {u_: RectTexture(W, H, a) for u_, a in units.items()}
+        for u_, t in tex.items():
+            t.bind(u_)
+            g.fn("glBindSampler", None, u32, u32)(u_, self.sampler)
+        g.fn("glActiveTexture", None, u32)(GL["TEXTURE0"] + 7)
+        common_state(W, H, "LESS")
+        self.fbo.attach(outs)
+        self.prog.use()
+        clear()
+        draw_points(self.vao, 1)
+        g.fn("glFinish", None)()
+        for u_ in tex:
+            g.fn("glBindSampler", None, u32, u32)(u_, 0)
+        g.check("render_compose draw")
+        return [o.read() for o in outs]

@@ -366,14 +366,18 @@ class Ref:
         return out[:n].copy(), mask
 
     # -- K10  SurfelMap::updateSurfels, second draw (SurfelMap.cpp:646-664; uniforms :360-376)
+    def generate_uniforms(self, pose, timestamp):
+        """the uniforms of initialize_program_ as SurfelMap.cpp:360-376 and :650-652 set them: [(name, value, kind)]"""
+        p = self.p
+        return [("fov_up", abs(np.float32(p.data_fov_up)), "f"), ("fov_down", abs(np.float32(p.data_fov_down)), "f"),
+                ("min_depth", p.min_depth, "f"), ("max_depth", p.max_depth, "f"), ("width", self.W, "f"), ("height", self.H, "f"),
+                ("pixel_size", self.pixel_size, "f"), ("log_prior", self.log_prior, "f"), ("pose", pose, "m"),
+                ("inv_pose", rigid_inverse_f32(pose), "m"), ("timestamp", timestamp, "i")]
+
     def generate(self, frame, radconf, integrated4, pose, timestamp):
         prog = "gen_surfels"
-        self._proj_uniforms(prog)
-        self._u(prog, "pixel_size", self.pixel_size)
-        self._u(prog, "log_prior", self.log_prior)
-        self._u(prog, "pose", pose, "m")
-        self._u(prog, "inv_pose", rigid_inverse_f32(pose), "m", required=False)
-        self._u(prog, "timestamp", timestamp, "i")
+        for name, value, kind in self.generate_uniforms(pose, timestamp):
+            self._u(prog, name, value, kind, required=name not in ("min_depth", "max_depth", "width", "height", "inv_pose"))
         self._tex(prog, "vertex_map", frame[0], LINEAR)
         self._tex(prog, "normal_map", frame[1], LINEAR)
         self._tex(prog, "semantic_map", frame[2], LINEAR)
