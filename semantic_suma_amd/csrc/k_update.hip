@@ -558,6 +558,24 @@ __device__ __forceinline__ Surfel4 load_surfel(const float4* __restrict__ sf, ui
   return r;
 }
 
+/* K9 needs ~110 launch-uniform values (two 4x4 matrices, the projection, 22 update parameters, 16 pointers) next to the
+ * exec masks of update_surfels.vert's nested branches: more than the 102 SGPRs of a wave.  Holding them all for the
+ * whole kernel made the compiler park 164 of them in VGPR lanes and fetch them back with a v_readlane at every use --
+ * 414 VALU instructions (+ 140 hazard nops) in the loop body of a kernel whose compute phase is VALU-bound.  Instead
+ * each phase of a trip re-reads what it needs from the kernel-argument segment (scalar loads through the constant
+ * cache: the scalar memory unit, not the VALU); the empty asm makes the pointer opaque so that the loads stay inside
+ * the phase instead of being hoisted out of the loop again. */
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(UPD_NO_ARG_RELOAD)
+#define UPD_ARG_RELOAD 1
+#endif
+#ifdef UPD_ARG_RELOAD
+typedef const UpdArgs __attribute__((address_space(4))) * UpdArgsK;
+__device__ __forceinline__ UpdArgsK upd_args_again(UpdArgsK p) {
+  asm volatile("" : "+s"(p));
+  return p;
+}
+#endif
+
 #ifdef SUMA_PHASE_TIMING
 __device__ unsigned long long g_k9_phase[PH_BLOCKS][9];
 /* host: PH_BLOCKS x 9 words (8 phase totals in 10 ns units + the number of launches the block took part in) */
@@ -606,6 +624,9 @@ __global__ void __launch_bounds__(K9_THREADS)
   if (a.write_pose && blockIdx.x == 0 && threadIdx.x == 0) write_pose_entry(a.poses_w, a.poses_inv_w, a.pose_idx, a.pose);
   /* the tile whose records wait in LDS for their output offset */
   uint32_t prev_tile = 0xffffffffu, prev_total = 0, prev_totalx = 0, buf = 0;
+#ifdef UPD_ARG_RELOAD
+  const UpdArgsK ka = (UpdArgsK)__builtin_amdgcn_kernarg_segment_ptr(); /* `a` is the kernel's only argument */
+#endif
   /* compacted stream-out of the tile in buffer pb: chunk c = (rank, 16-byte part) */
   auto stream_out = [&](uint32_t pb, uint32_t tile_id, uint32_t count, uint32_t countx) {
     const uint32_t prefix = s_prefix, prefix_x = XF ? s_prefix_x : 0u;
@@ -655,14 +676,24 @@ __global__ void __launch_bounds__(K9_THREADS)
         live[u] = idx[u] < S;
         in[u] = load_surfel(sf, live[u] ? idx[u] : 0u); /* out-of-range lanes read surfel 0 (S > 0 here), masked below */
       }
+#ifdef UPD_ARG_RELOAD
+      const UpdArgs aA = *upd_args_again(ka); /* this phase's arguments, fetched here */
+#else
+      const UpdArgs& aA = a;
+#endif
 #pragma unroll
-      for (int u = 0; u < K9_PER; ++u) pre[u] = k9_prepare(a, in[u]);
+      for (int u = 0; u < K9_PER; ++u) pre[u] = k9_prepare(aA, in[u]);
 #ifdef SUMA_PHASE_TIMING
       if (__float_as_uint(in[0].a.x) == 0x7fc12345u) ph_acc[7] += 1; /* consumes the surfel loads before the stamp */
 #endif
       PH(1); /* surfel loads + prepare issued */
 #pragma unroll
-      for (int u = 0; u < K9_PER; ++u) rec[u] = k9_gather(a, pre[u]);
+      for (int u = 0; u < K9_PER; ++u) rec[u] = k9_gather(aA, pre[u]);
+#ifdef UPD_ARG_RELOAD
+      const UpdArgs aB = *upd_args_again(ka);
+#else
+      const UpdArgs& aB = a;
+#endif
       uint32_t kept = 0;
       unsigned long long eb[K9_PER], xb[K9_PER];
       bool xt[K9_PER];
@@ -670,10 +701,10 @@ __global__ void __launch_bounds__(K9_THREADS)
       for (int u = 0; u < K9_PER; ++u) {
         Surfel4 o;
         int32_t mark_pix;
-        const bool keep = k9_finish(a, idx[u], in[u], pre[u], rec[u], o, &mark_pix) && live[u];
-        if (keep && mark_pix >= 0) a.integrated[mark_pix] = 1;
+        const bool keep = k9_finish(aB, idx[u], in[u], pre[u], rec[u], o, &mark_pix) && live[u];
+        if (keep && mark_pix >= 0) aB.integrated[mark_pix] = 1;
         bool in_tile;
-        emit[u] = in_active_area(a, o, &in_tile) && keep;
+        emit[u] = in_active_area(aB, o, &in_tile) && keep;
         const uint32_t slot = (uint32_t)u * K9_THREADS + threadIdx.x;
         xt[u] = in_tile && emit[u];
         xb[u] = XF ? __ballot(xt[u]) : 0ull;
@@ -797,6 +828,9 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
   const uint32_t xfirst = XF ? a.ds->n_ext_update : 0u;   /* K9's extracted records come first (map order) */
   const float color = pack_rgb(0.0f, 0.0f, 1.0f);
   uint32_t new_count = 0;
+#ifdef UPD_ARG_RELOAD
+  const UpdArgsK ka = (UpdArgsK)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
   for (;;) {
     __syncthreads();
     if (threadIdx.x == 0)
@@ -804,6 +838,11 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     __syncthreads();
     const uint32_t tile = s_tile;
     if (tile >= ntiles) break;
+#ifdef UPD_ARG_RELOAD
+    const UpdArgs aT = *upd_args_again(ka); /* the tile's arguments come from the argument segment again (see k9_update) */
+#else
+    const UpdArgs& aT = a;
+#endif
     /* A tile is SUMA_TILE consecutive items of the x-major emission order, i.e. (when H divides
      * SUMA_TILE) a patch of SUMA_TILE / H whole image columns.  Lanes walk the patch ROW-major so
      * that the map reads are 16-texel segments instead of one texel per 32 KiB row stride; the
@@ -824,27 +863,27 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     if (t < P) {
       const int32_t x = (int32_t)(t / (uint32_t)H), y = (int32_t)(t % (uint32_t)H);
       const size_t pix = (size_t)y * W + x;
-      const float4 v = a.V[pix], n = a.N[pix], rc = a.radius_conf[pix];
+      const float4 v = aT.V[pix], n = aT.N[pix], rc = aT.radius_conf[pix];
       /* export + clear of the K7 z-buffer */
-      const unsigned long long key = a.zbuf[pix];
-      a.index_map[pix] = (key == SUMA_EMPTY_KEY) ? 0u : (uint32_t)(key & 0xffffffffull) + 1u;
-      a.zbuf[pix] = SUMA_EMPTY_KEY;
+      const unsigned long long key = aT.zbuf[pix];
+      aT.index_map[pix] = (key == SUMA_EMPTY_KEY) ? 0u : (uint32_t)(key & 0xffffffffull) + 1u;
+      aT.zbuf[pix] = SUMA_EMPTY_KEY;
       bool invalid = (v.w < 1.0f) || (n.w < 1.0f);
       invalid = invalid || (rc.w < 0.5f);
-      const bool integrated = a.integrated[pix] != 0;
+      const bool integrated = aT.integrated[pix] != 0;
       const v3 vv = xyz(v), nn = xyz(n);
       const v3 view_dir = divs3(neg3(vv), len3(vv));
       gen = (!invalid && !integrated && (dot3(nn, view_dir) > 0.01f));
       if (gen) {
         const v3 ng = normalize3(nn);
-        const float4 sem = a.Sem[pix];
-        float conf = a.log_prior;
-        if (is_dynamic_label(sem.x * 255.0f)) conf = a.log_prior - 0.5f;
+        const float4 sem = aT.Sem[pix];
+        float conf = aT.log_prior;
+        if (is_dynamic_label(sem.x * 255.0f)) conf = aT.log_prior - 0.5f;
         s.a = f4(v.x, v.y, v.z, rc.x);
         s.b = f4(ng.x, ng.y, ng.z, conf);
-        s.c = f4(__uint_as_float((uint32_t)a.timestamp), color, 1.0f, (float)a.timestamp);
+        s.c = f4(__uint_as_float((uint32_t)aT.timestamp), color, 1.0f, (float)aT.timestamp);
         s.d = sem;
-        emit = in_active_area(a, s, &in_tile);
+        emit = in_active_area(aT, s, &in_tile);
       }
     }
     {
@@ -866,8 +905,8 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     if (threadIdx.x == 0)
       for (int w = 0; w < (int)TILE_WAVES; ++w) new_count += s_wave_b[w];
     if (threadIdx.x < 64) {
-      if (threadIdx.x == 0) lookback_publish(a.status, a.group, tile, br.total, a.epoch, brx.total);
-      const Pair pre = lookback_collect2<XF>(a.status, a.group, tile, a.epoch, threadIdx.x, &a.ds->overflow);
+      if (threadIdx.x == 0) lookback_publish(aT.status, aT.group, tile, br.total, aT.epoch, brx.total);
+      const Pair pre = lookback_collect2<XF>(aT.status, aT.group, tile, aT.epoch, threadIdx.x, &aT.ds->overflow);
       if (threadIdx.x == 0) {
         s_prefix = pre.a;
         if (XF) s_prefix_x = pre.x;
@@ -877,28 +916,28 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
     if (emit) {
       const uint32_t rk = s_rank[q];
       uint64_t dst = (uint64_t)base + s_prefix + (XF ? (rk & 0xffffu) : rk);
-      if (dst < a.max_surfels) {
-        store_surfel(a.out, (uint32_t)dst, s);
+      if (dst < aT.max_surfels) {
+        store_surfel(aT.out, (uint32_t)dst, s);
         if (XF) {
           if (in_tile) {
             const uint64_t xr = (uint64_t)xfirst + s_prefix_x + (rk >> 16);
-            if (xr < SUMA_EXTRACT_CAPACITY && (uint64_t)xbase + xr < a.x_cap) store_surfel(a.x_arena, (uint32_t)(xbase + xr), s);
+            if (xr < SUMA_EXTRACT_CAPACITY && (uint64_t)xbase + xr < aT.x_cap) store_surfel(aT.x_arena, (uint32_t)(xbase + xr), s);
           }
-        } else if (a.ex_flags != nullptr) {
-          a.ex_flags[dst] = in_tile ? 1 : 0;
+        } else if (aT.ex_flags != nullptr) {
+          aT.ex_flags[dst] = in_tile ? 1 : 0;
         }
       }
     }
     if (tile == ntiles - 1 && threadIdx.x == 0) {
       uint64_t kept = (uint64_t)s_prefix + br.total;
       uint64_t total = (uint64_t)base + kept;
-      a.ds->n_kept_data = (uint32_t)kept;
-      if (total > a.max_surfels) {
-        total = a.max_surfels;
-        atomicOr(&a.ds->overflow, 1u);
+      aT.ds->n_kept_data = (uint32_t)kept;
+      if (total > aT.max_surfels) {
+        total = aT.max_surfels;
+        atomicOr(&aT.ds->overflow, 1u);
       }
-      a.ds->n_surfels = (uint32_t)total; /* the compaction target becomes the active map */
-      if (XF) a.ds->n_extracted = xfirst + s_prefix_x + brx.total;
+      aT.ds->n_surfels = (uint32_t)total; /* the compaction target becomes the active map */
+      if (XF) aT.ds->n_extracted = xfirst + s_prefix_x + brx.total;
     }
   }
   if (threadIdx.x == 0 && new_count)
