@@ -13,7 +13,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "semantic_suma_amd", "csrc")
+CSRC = os.environ.get("SUMA_CSRC", os.path.join(ROOT, "semantic_suma_amd", "csrc"))
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-mllvm",
          "-amdgpu-kernarg-preload-count=16", "-w"]
 
