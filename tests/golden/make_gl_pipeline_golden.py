@@ -4,7 +4,7 @@ SurfelMapping::processScan AS A REAL OPENGL IMPLEMENTATION EXECUTES IT -- every 
 (/root/reference/src/shader) run by Mesa llvmpipe, the host code between the passes restated in numpy
 (oracle/glpipeline.py).  The scans are the seeded synthetic ones (semantic_suma_amd/synth.py), so the GPU suite can
 run the same scans through the HIP pipeline and compare (tests/test_gpu_gl_golden.py) without Mesa or /root/reference.
-Run from the repo root:   python tests/golden/make_gl_pipeline_golden.py
+Run from the repo root:   python tests/golden/make_gl_pipeline_golden.py [bench]     (bench: 64 x 2048, six scans)
 """
 import os
 import sys
@@ -17,7 +17,7 @@ from oracle import glpipeline, glref  # noqa: E402
 from semantic_suma_amd import synth  # noqa: E402
 from semantic_suma_amd.types import params_with_size  # noqa: E402
 
-W, H, N, ITER = 900, 64, 8, 10
+W, H, N, ITER = (2048, 64, 6, 10) if (len(sys.argv) > 1 and sys.argv[1] == "bench") else (900, 64, 8, 10)
 p = params_with_size(W, H)
 g = glpipeline.GLPipeline(p)
 poses, incs, counts = [], [], []

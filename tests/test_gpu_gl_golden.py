@@ -39,16 +39,18 @@ def test_hip_render_agrees_with_opengl(oracle_lib):
     assert_bit_equal(n, ora.map_frame(1).map(1), "render_active normal map")
 
 
-def test_hip_pipeline_agrees_with_the_scan_loop_in_opengl():
+@pytest.mark.parametrize("fixture,tol_m,tol_rad", [("gl_pipeline_900x64.npz", 5e-2, 2e-3), ("gl_pipeline_2048x64.npz", 5e-3, 5e-4)])
+def test_hip_pipeline_agrees_with_the_scan_loop_in_opengl(fixture, tol_m, tol_rad):
     """tests/golden/gl_pipeline_900x64.npz (tests/golden/make_gl_pipeline_golden.py): eight scans through
     SurfelMapping::processScan with EVERY pass executed by a real OpenGL implementation from the reference's own shader
     text (oracle/glpipeline.py).  The HIP pipeline on the same seeded scans: trajectory within 5 cm / 2e-3 rad (measured
     2 cm, acquired in the cold minimisation of the second scan, where the GL path's own fp32 blend-order noise is
-    amplified -- DESIGN.md section 2), map sizes within 0.3 %, update counters within 0.5 %."""
+    amplified -- DESIGN.md section 2), map sizes within 0.3 %, update counters within 0.5 %.  At the bench geometry
+    64 x 2048 (six scans) the two paths stay within 1.6 mm / 2.3e-4 rad; asserted 5 mm / 5e-4 rad."""
     import math
     from conftest import get_scan
     from semantic_suma_amd import core
-    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gl_pipeline_900x64.npz"))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
     W, n, iters = int(z["W"]), int(z["scans"]), int(z["iterations"])
     hp = core.SurfelMapping(params_with_size(W, int(z["H"])))
     for k in range(n):
@@ -57,9 +59,9 @@ def test_hip_pipeline_agrees_with_the_scan_loop_in_opengl():
         D = np.linalg.inv(z["poses"][k]) @ hp.getCurrentPose()
         dt = float(np.linalg.norm(D[:3, 3]))
         dr = math.acos(max(-1.0, min(1.0, 0.5 * (np.trace(D[:3, :3]) - 1.0))))
-        assert dt <= 5e-2 and dr <= 2e-3, f"scan {k}: {dt:.2e} m / {dr:.2e} rad from the GL path"
+        assert dt <= tol_m and dr <= tol_rad, f"scan {k}: {dt:.2e} m / {dr:.2e} rad from the GL path"
         gl_map, gl_upd, gl_new = (int(v) for v in z["counts"][k][:3])
         su, sn, _, _ = hp.map.counts()
         assert abs(hp.map.size() - gl_map) <= 0.003 * gl_map + 5, (k, hp.map.size(), gl_map)
         assert abs(sn - gl_new) <= 0.02 * gl_new + 20, (k, sn, gl_new)
-    assert float(np.linalg.norm(hp.getCurrentPose()[:3, 3])) > 5.0
+    assert float(np.linalg.norm(hp.getCurrentPose()[:3, 3])) > 4.0
