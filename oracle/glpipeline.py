@@ -3,8 +3,9 @@
 The closest thing to "running the reference" these machines allow: every GL pass of the hot path (K1-K12) is the
 reference's GLSL text from /root/reference/src/shader, compiled and executed by Mesa llvmpipe through oracle/glref.py;
 the host code between the passes -- what SurfelMapping.cpp, SurfelMap.cpp, Frame2Model.cpp and LieGaussNewton.cpp do
-with glow, Eigen and the CPU -- is restated here in numpy, each step citing the lines it follows.  Loop closures, the
-pose graph and submap paging are outside (the sequences used stay inside one submap window; asserted).
+with glow, Eigen and the CPU -- is restated here in numpy, each step citing the lines it follows, including the submap
+window (updateActiveSubmaps: tiles pushed for extraction, extract_surfels through transform feedback, parked tiles
+appended when they come back).  Loop closures and the pose graph are outside.
 
 Used by tests/test_gl_pipeline.py only: it puts the end-to-end acceptance criterion of the task -- poses within
 1e-4 m / 1e-5 rad per ICP iteration of the reference's OpenGL path on identical scans -- on a real GL implementation
@@ -36,6 +37,11 @@ class GLPipeline:
         self.k7, self.k8 = gl.IndexMap(p), gl.RadiusConfidence(p)
         self.k9, self.k10 = gl.SurfelUpdate(p), gl.SurfelGenerate(p)
         self.k11 = gl.SurfelFilter("copy_surfels.vert")
+        self.k12 = gl.SurfelFilter("extract_surfels.vert")
+        self.origin = [0, 0]       # submap_origin_
+        self.extraction = []       # extraction_buffer_ (tiles waiting to be parked)
+        self.cache = {}            # submapCache_(i, j).surfels
+        self.extractions = 0
         self.timestamp = 0
         self.surfels = np.zeros((0, 16), dtype=f32)
         eye_cm = np.eye(4, dtype=f32).reshape(-1)
@@ -46,6 +52,45 @@ class GLPipeline:
         self.counts = {}
         p_unstable = f32(0.1)  # SurfelMapping.cpp:108-109
         self.log_unstable = f32(math.log(float(p_unstable / (f32(1.0) - p_unstable))))
+
+    def center(self, i, j):
+        """submapIndex2center, SurfelMap.cpp:704-706"""
+        return (f32(2.0 * i * self.p.submap_extent), f32(2.0 * j * self.p.submap_extent))
+
+    def update_active_submaps(self, pose32, poses):
+        """SurfelMap::updateActiveSubmaps (SurfelMap.cpp:744-824) and extractSurfels (:708-742)"""
+        p = self.p
+        dim, ext = int(p.submap_dimension), f32(p.submap_extent)
+        cx, cy = self.center(*self.origin)
+        changex, changey = f32(pose32[0, 3]) - cx, f32(pose32[1, 3]) - cy
+        limit = f32(1.1) * ext
+
+        def append(i, j):  # :775-780, 801-806: the parked tile comes back behind the active surfels
+            tile = self.cache.get((i, j))
+            if tile is not None and tile.shape[0]:
+                room = int(p.max_surfels) - self.surfels.shape[0]
+                self.surfels = np.concatenate([self.surfels, tile[:max(room, 0)]])
+
+        if abs(changex) > limit:
+            d = -1 if changex < 0 else 1
+            self.extraction += [(self.origin[0] - d * dim, self.origin[1] + k) for k in range(-dim, dim + 1)]
+            self.origin[0] += d
+            for k in range(-dim, dim + 1):
+                append(self.origin[0] + d * dim, self.origin[1] + k)
+        if abs(changey) > limit:
+            d = -1 if changey < 0 else 1
+            self.extraction += [(self.origin[0] + r, self.origin[1] - d * dim) for r in range(-dim, dim + 1)]
+            self.origin[1] += d
+            for r in range(-dim, dim + 1):
+                append(self.origin[0] + r, self.origin[1] + d * dim)
+        while self.extraction:  # extractSurfels(partial_extraction_): tiles are taken from the back
+            i, j = self.extraction.pop()
+            tile = self.k12.run([self.surfels], poses, self.center(i, j), ext)
+            self.cache[(i, j)] = tile[:500000]  # extractBuffer_.reserve(500000), :279
+            self.extractions += 1
+            self.last_extraction = (i, j)
+            if p.partial_extraction:
+                break
 
     def conf_threshold(self):
         """SurfelMapping::getConfidenceThreshold, SurfelMapping.cpp:333-340 (time_init = 10)"""
@@ -111,9 +156,10 @@ class GLPipeline:
         mask4[..., 0] = mask > 0.5
         new = self.k10.run(self.ref.generate_uniforms(pose32, t), frame, rc, mask4)
         extent = f32(2.0) * f32(p.submap_dimension) * f32(p.submap_extent) + f32(p.submap_extent)  # copySurfels, :667-677
-        self.surfels = self.k11.run([upd, new], poses, (f32(0.0), f32(0.0)), extent)
-        # updateActiveSubmaps(), :744-824: no shift inside the runs compared here
-        assert abs(float(pose32[0, 3])) <= 1.1 * p.submap_extent and abs(float(pose32[1, 3])) <= 1.1 * p.submap_extent
+        if p.partial_extraction and self.extraction:
+            extent = extent + f32(2.0) * f32(p.submap_extent)  # :674-677
+        self.surfels = self.k11.run([upd, new], poses, self.center(*self.origin), extent)
+        self.update_active_submaps(pose32, poses)
         self.counts = dict(updated=int(upd.shape[0]), new=int(new.shape[0]), map=int(self.surfels.shape[0]),
                            integrated=int((mask > 0.5).sum()), index=int((idx > 0).sum()))
         self.timestamp += 1
