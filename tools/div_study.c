@@ -3,7 +3,7 @@
  * rounded for finite operands in a safe exponent range, WHATEVER the hardware's 1-ulp reciprocal approximation returns?
  * If so, three quotients by one denominator (v / length(v), the barycentrics of a triangle) cost 3 + 3 x 5 instructions
  * instead of 3 x 11, behind one exponent-range test.  CPU emulation with fmaf (exactly the GPU's v_fma_f32):
- *     gcc -O2 -ffp-contract=off tools/div_study.c -o /tmp/div_study -lm && /tmp/div_study 400000000
+ *     gcc -O2 -ffp-contract=off -Itools tools/div_study.c -o /tmp/div_study -lm && /tmp/div_study 400000000 [hard]
  */
 #include <math.h>
 #include <stdint.h>
@@ -16,16 +16,10 @@ static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static uint64_t s = 0x9E3779B97F4A7C15ull;
 static inline uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
 
+#include "exact_div.h" /* the very functions a kernel would use */
+
 /* r0: any approximation of 1/y within 1 ulp (v_rcp_f32) */
-static inline float div_core(float x, float y, float r0) {
-  float e = fmaf(-y, r0, 1.0f);
-  float r = fmaf(e, r0, r0);
-  float q = x * r;
-  float e1 = fmaf(-y, q, x);
-  q = fmaf(e1, r, q);
-  float e2 = fmaf(-y, q, x);
-  return fmaf(e2, r, q);
-}
+static inline float div_core(float x, float y, float r0) { return exdiv_quot(x, y, exdiv_refine(y, r0)); }
 
 int main(int argc, char** argv) {
   uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull, bad = 0, tested = 0;
