@@ -56,7 +56,6 @@ def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
             ct = p.confidence_threshold if k >= 10 else float(np.float32((1.0 - k / 10.0) * math.log(0.1 / 0.9) + np.float32(k / 10.0) * np.float32(p.confidence_threshold)))
             ora.map_render(pose32, pose32, ct, out)
             model = ora.map_frame(1)
-            saved = ora.params.max_iterations, ora.params.stopping_threshold, ora.params.delta
             pp = params_with_size(W, max_iterations=ITER, stopping_threshold=0.0, delta=0.0)
             ora.set_params(pp)
             _, hist, st = ora.minimize(cur, model, op.last_increment(), history_cap=ITER + 1)
@@ -67,8 +66,7 @@ def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
             for it in range(ITER):
                 b = g.k6.run(cm, mm, hist[it], it)
                 dx = np.linalg.solve(b[:36].reshape(6, 6).astype(np.float64), -b[36:42].astype(np.float64))
-                from oracle import pyref
-                Tn = pyref.se3_exp(dx) @ hist[it]
+                Tn = glp.pyref.se3_exp(dx) @ hist[it]
                 dt, dr = pose_delta(Tn, hist[it + 1])
                 worst = (max(worst[0], dt), max(worst[1], dr))
                 steps.append((k, it, dt, dr, st_valid))
@@ -155,7 +153,7 @@ def test_gl_pipeline_through_the_submap_window(glp, oracle_lib):
             want, got = ora.map_cache_tile(int(ei), int(ej)).shape[0], g.cache[g.last_extraction].shape[0]
             assert abs(want - got) <= 0.01 * want + 10, f"scan {n}: tile ({ei},{ej}) {got} surfels in GL, {want} in the oracle"
             parked = max(parked, want)
-        n_o, n_g = ora.map_size(), g.counts["map"] if False else g.surfels.shape[0]
+        n_o, n_g = ora.map_size(), g.surfels.shape[0]
         print("step %d (scan %d): %.2e m %.2e rad | origin %s | map %d / %d | extractions %d" % (n, k, dt, dr, tuple(g.origin), n_o, n_g, count))
         assert dt <= 5e-2 and dr <= 3e-3, f"scan {n}: {dt:.2e} m / {dr:.2e} rad apart"
         assert abs(n_o - n_g) <= 0.005 * n_o + 10

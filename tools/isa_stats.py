@@ -5,7 +5,6 @@ nops, IEEE division sequences (v_div_fixup), scalar and vector memory instructio
 compiler.  This is what found K9's spilled arguments.
     python tools/isa_stats.py [file.hip ...] [-D...]        (default: the four kernel files)
 """
-import collections
 import os
 import re
 import subprocess
