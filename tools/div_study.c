@@ -23,7 +23,8 @@ static inline float div_core(float x, float y, float r0) { return exdiv_quot(x, 
 
 int main(int argc, char** argv) {
   uint64_t n = argc > 1 ? strtoull(argv[1], 0, 10) : 100000000ull, bad = 0, tested = 0;
-  const int hard = argc > 2; /* any second argument: the near-boundary numerators */
+  const int ints = argc > 2 && argv[2][0] == 'i'; /* "int": integer operands as in k_render's barycentrics */
+  const int hard = argc > 2 && !ints;             /* any other second argument: the near-boundary numerators */
   for (uint64_t i = 0; i < n; ++i) {
     uint64_t a = rnd(), b = rnd();
     /* sign, exponent in [-60, 60], random mantissa; every 8th pair with structured mantissas (all ones, one bit, equal) */
@@ -33,7 +34,13 @@ int main(int argc, char** argv) {
     if ((i & 31) == 0) { my = mx; }
     uint32_t ex = 127 - 60 + (uint32_t)((a >> 24) % 121), ey = 127 - 60 + (uint32_t)((b >> 24) % 121);
     float x = u2f(((uint32_t)(a >> 63) << 31) | (ex << 23) | mx), y = u2f(((uint32_t)(b >> 63) << 31) | (ey << 23) | my);
-    if (hard) { /* numerators whose quotient lies next to a rounding boundary: x = RN(y * (q + ulp(q) / 2)) */
+    if (ints) { /* the barycentrics of k_render: integer edge functions 0 <= w <= area < 2^46 converted to float */
+      uint64_t area = 1 + (b >> (18 + (int)((a >> 58) % 40))), w = (a >> 18) % (area + 1);
+      if ((i & 63) == 0) w = 0;
+      if ((i & 127) == 1) w = area;
+      x = (float)(long long)w;
+      y = (float)(long long)area;
+    } else if (hard) { /* numerators whose quotient lies next to a rounding boundary: x = RN(y * (q + ulp(q) / 2)) */
       float qm = u2f((127u << 23) | mx);
       double mid = (double)qm + ldexp(1.0, -24);
       x = (float)((double)y * mid);
@@ -50,6 +57,6 @@ int main(int argc, char** argv) {
     }
   }
   printf("%llu %squotients (exponents of x, y in [-60, 60], reciprocal approximations -1 / 0 / +1 ulp): %llu mismatches\n",
-         (unsigned long long)tested, hard ? "near-boundary " : "", (unsigned long long)bad);
+         (unsigned long long)tested, ints ? "integer-operand " : hard ? "near-boundary " : "", (unsigned long long)bad);
   return bad != 0;
 }
