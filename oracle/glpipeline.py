@@ -5,7 +5,8 @@ reference's GLSL text from /root/reference/src/shader, compiled and executed by 
 the host code between the passes -- what SurfelMapping.cpp, SurfelMap.cpp, Frame2Model.cpp and LieGaussNewton.cpp do
 with glow, Eigen and the CPU -- is restated here in numpy, each step citing the lines it follows, including the submap
 window (updateActiveSubmaps: tiles pushed for extraction, extract_surfels through transform feedback, parked tiles
-appended when they come back).  Loop closures and the pose graph are outside.
+appended when they come back) and the frame-to-frame fallback minimisation after a track loss.  Loop closures and the
+pose graph are outside.
 
 Used by tests/test_gl_pipeline.py only: it puts the end-to-end acceptance criterion of the task -- poses within
 1e-4 m / 1e-5 rad per ICP iteration of the reference's OpenGL path on identical scans -- on a real GL implementation
@@ -49,6 +50,9 @@ class GLPipeline:
         self.current_pose = np.eye(4)
         self.last_increment = np.eye(4)
         self.frame = None
+        self.last_frame = None
+        self.k6_fallback = None
+        self.track_loss = 0
         self.counts = {}
         p_unstable = f32(0.1)  # SurfelMapping.cpp:108-109
         self.log_unstable = f32(math.log(float(p_unstable / (f32(1.0) - p_unstable))))
@@ -126,6 +130,7 @@ class GLPipeline:
         # initialize() + preprocess(), SurfelMapping.cpp:181-187, 323-358
         gv, gs = self.k1.run(points, labels, probs, t, int(p.label_offset), int(p.prob_offset))
         gn, _, gr = self.k23.run(gv, gs)
+        self.last_frame = self.frame  # initialize(), SurfelMapping.cpp:323-331: the frames swap
         frame = self.frame = (gv, gn, gr)
         pose32 = self.current_pose.astype(f32)
         if t > 0:  # updatePose(), :372-476
@@ -134,7 +139,17 @@ class GLPipeline:
             delta = np.linalg.inv(self.last_increment) @ increment
             t_err = float(np.linalg.norm(delta[:3, 3]))
             r_err = math.acos(max(-1.0, min(1.0, 0.5 * (np.trace(delta[:3, :3]) - 1.0))))
-            assert not (t > 1 and (t_err > 0.4 or r_err > 0.1)), "the fallback ICP (:438-449) is outside this restatement"
+            if t > 1 and (f32(t_err) > 0.4 or f32(r_err) > 0.1) and p.fallback_mode:
+                # track loss, SurfelMapping.cpp:438-449: frame-to-frame with the fallback gates, same start
+                self.track_loss += 1
+                if self.k6_fallback is None:
+                    import copy
+                    pf = copy.copy(p)
+                    pf.icp_max_distance, pf.icp_max_angle = p.fallback_max_distance, p.fallback_max_angle
+                    self.k6_fallback = gl.Jacobians(pf)
+                k6, self.k6 = self.k6, self.k6_fallback
+                increment = self.minimize(frame, self.last_frame, self.last_increment, iterations)
+                self.k6 = k6
             self.current_pose = self.current_pose @ increment
             self.last_increment = increment
         # updateMap() -> SurfelMap::update(pose, frame), SurfelMap.cpp:492-584
