@@ -110,6 +110,10 @@ def test_depth_quantisation_rule(gl, oracle_lib):
     assert np.array_equal(db < da, second_wins)
     assert 0.25 < second_wins.mean() < 0.6 and (da == db).mean() > 0.1  # the test does probe ties and near-ties
     assert np.array_equal(zwin.ravel(), zw(np.where(second_wins, zb, za)))  # gl_FragCoord.z is z_w, not z01
+    # GL_LEQUAL (render_composed, SurfelMap.cpp:1126): on equal 24-bit depth the LATER primitive replaces the earlier one
+    win_le, _ = gl.QuadRaster(w, h).run(cn, np.arange(2 * n), disc=False, flat_z=True, depth_func="LEQUAL")
+    assert np.array_equal(db <= da, win_le.ravel() >= n)
+    assert (win_le.ravel() >= n).sum() > second_wins.sum()  # the ties changed hands
 
 
 def test_quads_with_disc_and_depth_test(gl, scene):
@@ -435,3 +439,33 @@ def test_reference_radius_and_compose_shaders_in_gl(gl, oracle_lib):
     for m in range(3):
         assert np.array_equal(gotc[m].view(np.uint32), wantc[m].view(np.uint32)), f"K5 attachment {m}"
     print(f"K8 in GL: radius bit-equal on {k8_exact:.4f} of the texels; K5 equal on every texel")
+
+
+
+def test_reference_render_composed_in_gl(gl, scene, oracle_lib):
+    """SurfelMap::render_composed (SurfelMap.cpp:1116-1165: GL_LEQUAL, the old surfels from pose_old, then -- without
+    clearing -- the new ones from pose_new into the same depth buffer) through the reference's shaders in llvmpipe against
+    the oracle's composed frame.  The 12-scan map is given timestamp 106, so that timestamp_ - composeSurfelAge_ = 6 makes
+    the surfels of scans 0-5 "old" and those of scans 6-11 "new" and both passes draw: >= 97 % of the texels carry the
+    same surfel."""
+    p, ctx, pose, ts = scene["p"], scene["ctx"], scene["pose"], 106
+    surfels, poses = ctx.map_surfels(), ctx.map_poses(int(scene["ts"]) + 1)
+    ora = oracle_lib.Oracle(p)
+    ora.map_upload(surfels, ts)
+    ora.map_update_poses(poses.reshape(-1, 4, 4).transpose(0, 2, 1))
+    pose_old = pose.copy()
+    pose_old[0, 3] -= 0.4  # a loop-closure candidate seen from a slightly different place
+    ora.map_render_composed(pose_old, pose, 0.0)
+    want = [ora.map_frame(2).map(m) for m in range(2)]
+    R = gl.SurfelRenderer(p)
+    pt = poses.reshape(-1, 16)
+    tg = R.render_pass(surfels, pt, pose_old, 0.0, ts - 100, True, depth_func="LEQUAL")
+    old_only = tg[0].read()[..., 3] > 0.5
+    tg = R.render_pass(surfels, pt, pose, 0.0, ts - 100, False, depth_func="LEQUAL", targets=tg, clear_first=False)
+    got = [t.read() for t in tg]
+    va, vb = want[0][..., 3] > 0.5, got[0][..., 3] > 0.5
+    assert va.sum() > 30000 and old_only.sum() > 5000 and vb.sum() > old_only.sum() + 5000, "both passes must draw"
+    same = va & vb & np.all(np.abs(want[0] - got[0]) <= 1e-4 * (1.0 + np.abs(want[0])), axis=-1)
+    print(f"render_composed in GL: {same.sum()} of {max(va.sum(), vb.sum())} texels carry the same surfel")
+    assert same.sum() >= 0.97 * max(va.sum(), vb.sum())
+    assert np.all(np.abs(want[1][same] - got[1][same]) <= 1e-4)
