@@ -175,3 +175,19 @@ def test_gl_pipeline_takes_the_fallback_like_the_oracle(glp, oracle_lib):
         assert op.track_loss() == g.track_loss, f"step {n}: fallback decision"
         assert dt <= 1e-1 and dr <= 5e-3, f"step {n}: {dt:.2e} m / {dr:.2e} rad apart"
     assert g.track_loss >= 1, "the sequence was meant to trip the fallback"
+
+
+@pytest.mark.parametrize("fixture,tol_m,tol_rad", [("gl_pipeline_900x64.npz", 5e-2, 2e-3), ("gl_pipeline_2048x64.npz", 5e-3, 5e-4)])
+def test_oracle_agrees_with_the_committed_gl_trajectories(oracle_lib, fixture, tol_m, tol_rad):
+    """The committed GL-made trajectories (tests/golden/make_gl_pipeline_golden.py; no Mesa needed here) against the
+    oracle on the same seeded scans -- the CPU twin of tests/test_gpu_gl_golden.py."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", fixture))
+    Wf, n, iters = int(z["W"]), int(z["scans"]), int(z["iterations"])
+    op = oracle_lib.OraclePipeline(params_with_size(Wf, int(z["H"])), threads=max(1, min(8, os.cpu_count() or 1)))
+    for k in range(n):
+        pts, lab, prob, _ = get_scan(k, Wf, True)
+        op.process_scan(pts, lab, prob, fixed_iterations=iters)
+        dt, dr = pose_delta(z["poses"][k], op.pose())
+        assert dt <= tol_m and dr <= tol_rad, f"scan {k}: {dt:.2e} m / {dr:.2e} rad from the GL path"
+        gl_map = int(z["counts"][k][0])
+        assert abs(op.ctx.map_size() - gl_map) <= 0.003 * gl_map + 5
