@@ -101,6 +101,79 @@ def available():
         return False
 
 
+# --- the CONTROL of tests/test_gl_pipeline.py: the reference's shader text with the driver's transcendentals replaced.
+# GLSL leaves the accuracy of asin / acos / atan to the implementation (GLSL 4.50 section 4.7.1: "undefined" for the
+# angle functions); llvmpipe's asin is off by up to 3.9e-4 rad.  This prelude -- the Cephes
+# kernels of include/suma_detmath.h (sdm_atan :79-99, sdm_atan2 :102-117, sdm_asin :124-148, sdm_acos :150-155) restated
+# in GLSL, one IEEE operation per statement, `precise` so that the GLSL compiler neither fuses nor reassociates -- is put
+# between the #version line and the reference's text, followed by three #defines.  Not one character of the reference's
+# shader is changed: what changes is the library the GL implementation evaluates its three angle functions with.
+DETMATH_PRELUDE = """
+float sdm_atan1(float xx) {
+  precise float x = abs(xx);
+  precise float y = 0.0;
+  if (x > 2.414213562373095) { y = 1.57079632679489661923; x = -(1.0 / x); }
+  else if (x > 0.4142135623730950) { y = 0.78539816339744830962; precise float a = x - 1.0; precise float b = x + 1.0; x = a / b; }
+  precise float z = x * x;
+  precise float p = 8.05374449538e-2 * z;
+  p = p + -1.38776856032e-1;
+  p = p * z; p = p + 1.99777106478e-1;
+  p = p * z; p = p + -3.33329491539e-1;
+  p = p * z; p = p * x; p = p + x;
+  y = y + p;
+  return (xx < 0.0) ? -y : y;
+}
+float sdm_atan_gl(float yx) { return sdm_atan1(yx); }
+float sdm_atan_gl(float y, float x) {
+  if (isnan(x) || isnan(y)) return x + y;
+  if (x == 0.0) { if (y > 0.0) return 1.57079632679489661923; if (y < 0.0) return -1.57079632679489661923; return 0.0; }
+  precise float q = y / x;
+  precise float z = sdm_atan1(q);
+  if (x < 0.0) { if (y < 0.0) z = z - 3.14159265358979323846; else z = z + 3.14159265358979323846; }
+  return z;
+}
+float sdm_asin_gl(float xx) {
+  precise float a = abs(xx);
+  if (!(a <= 1.0)) return uintBitsToFloat(0x7fc00000u);
+  if (a < 1.0e-4) return xx;
+  precise float x; precise float z; bool flag = false;
+  if (a > 0.5) { z = 1.0 - a; z = 0.5 * z; x = sqrt(z); flag = true; } else { x = a; z = x * x; }
+  precise float p = 4.2163199048e-2 * z; p = p + 2.4181311049e-2;
+  p = p * z; p = p + 4.5470025998e-2;
+  p = p * z; p = p + 7.4953002686e-2;
+  p = p * z; p = p + 1.6666752422e-1;
+  p = p * z; p = p * x; z = p + x;
+  if (flag) { z = z + z; z = 1.57079632679489661923 - z; }
+  return (xx < 0.0) ? -z : z;
+}
+float sdm_acos_gl(float x) {
+  if (!(abs(x) <= 1.0)) return uintBitsToFloat(0x7fc00000u);
+  if (x < -0.5) { precise float t = 1.0 + x; t = 0.5 * t; t = sdm_asin_gl(sqrt(t)); t = 2.0 * t; return 3.14159265358979323846 - t; }
+  if (x > 0.5) { precise float t = 1.0 - x; t = 0.5 * t; t = sdm_asin_gl(sqrt(t)); return 2.0 * t; }
+  return 1.57079632679489661923 - sdm_asin_gl(x);
+}
+#define asin sdm_asin_gl
+#define acos sdm_acos_gl
+#define atan sdm_atan_gl
+"""
+
+_prelude = [""]
+
+
+class transcendentals:
+    """`with glref.transcendentals("detmath"):` -- programs BUILT inside the block get DETMATH_PRELUDE (above) in front
+    of the reference's text; "driver" (the default) leaves the GL implementation's own functions in place"""
+
+    def __init__(self, which):
+        self.text = {"driver": "", "detmath": DETMATH_PRELUDE}[which]
+
+    def __enter__(self):
+        self.saved, _prelude[0] = _prelude[0], self.text
+
+    def __exit__(self, *exc):
+        _prelude[0] = self.saved
+
+
 def shader_source(name):
     """a shader of the reference with its #include lines resolved (glow does that at load time)"""
     import re
@@ -110,7 +183,12 @@ def shader_source(name):
     def inc(m):
         with open(os.path.join(os.path.dirname(SHADER_DIR), m.group(1))) as g:
             return g.read()
-    return re.sub(r'#include\s+"([^"]+)"', inc, src)
+    src = re.sub(r'#include\s+"([^"]+)"', inc, src)
+    if _prelude[0]:
+        # behind the #version line, which stays the reference's; `precise` comes with GL_ARB_gpu_shader5
+        src = re.sub(r"^(\s*#version[^\n]*\n)", lambda m: m.group(1) + "#extension GL_ARB_gpu_shader5 : require\n" + _prelude[0],
+                     src, count=1)
+    return src
 
 
 u32, i32, f32, vp = C.c_uint, C.c_int, C.c_float, C.c_void_p
@@ -469,7 +547,7 @@ class Jacobians:
     emits 16 points into a 2 x 8 RGB32F target with GL_ONE / GL_ONE blending.  Returns the 48 floats the host reads
     back (:214-227 unpacks them)."""
 
-    def __init__(self, params, entries_per_kernel=64):
+    def __init__(self, params, entries_per_kernel=64, order=None):
         import math
         p = self.p = params
         self.epk = entries_per_kernel
@@ -485,6 +563,8 @@ class Jacobians:
                       fov_up=fov_up, fov_down=fov_down, fov=float(np.float32(fov_up) + np.float32(fov_down)),
                       min_depth=float(p.min_depth), max_depth=float(p.max_depth), cutoff_threshold=0.0)
         coords = np.array([(i + 0.5, j + 0.5) for i in range(0, self.W, entries_per_kernel) for j in range(self.H)], dtype=np.float32)
+        if order is not None:  # control experiment only (tests/test_gl_controls.py): the same points, drawn in another order
+            coords = np.ascontiguousarray(coords[np.asarray(order)])
         self.n = coords.shape[0]
         g = Context.get()
         self.vbo = Buffer(coords)

@@ -33,18 +33,22 @@ def glp():
 
 
 def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
-    """Teacher-forced, per ICP iteration: from the oracle's pose before iteration k, ONE Gauss-Newton step with the
-    reference's Frame2Model_jacobians shaders in llvmpipe, on the oracle's frames, against the oracle's pose after
-    iteration k.  north_star's tolerance for the HIP path is 1e-4 m / 1e-5 rad per iteration against "the reference
-    OpenGL path"; what this measures is how sharply that path defines itself: its 6 x 6 system is an fp32 blend-add over
-    ~10^4 fragments in rasterisation order, a handful of pairs sit on a gate and flip with the driver's atan / asin, and
-    one step of it lands 0.4 .. 10 x 10^-4 m and 0.3 .. 11 x 10^-5 rad from the exact-sum, deterministic-math step
-    (measured over 40 steps; no trend over the iterations, i.e. noise, not bias).  Asserted: every step within 2e-3 m /
-    3e-4 rad, the median within 3e-4 m / 5e-5 rad."""
+    """THE ACCEPTANCE LINE.  Teacher-forced, per ICP iteration: from the oracle's pose before iteration k, ONE Gauss-Newton
+    step with the reference's Frame2Model_jacobians shaders executed by llvmpipe, on the oracle's frames, against the
+    oracle's pose after iteration k -- the pose the HIP path reproduces bit for bit.  north_star: "pose delta within
+    1e-4 m / 1e-5 rad per ICP iteration" of the reference OpenGL path.
+
+    Round 4 ran this with the DRIVER'S asin / atan (llvmpipe: up to 3.9e-4 rad off, a twentieth of an image row) and saw
+    0.4 .. 10 x 10^-4 m; round 5's controls (tests/test_gl_controls.py) show that this was the driver's asin alone moving
+    ~10 pairs per iteration across a gate -- GL against itself under a permuted draw order differs by 4e-7 m, i.e. fp32
+    blend order is three orders of magnitude smaller.  Here the reference's shader text runs unchanged with its three angle
+    functions #defined to the specified ones (oracle/glref.py::DETMATH_PRELUDE -- GLSL leaves their accuracy to the
+    implementation): every one of the 40 steps is asserted within 1e-4 m / 1e-5 rad (measured: 3e-7 m / 3e-8 rad)."""
     p = params_with_size(W)
     op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
-    g = glp.GLPipeline(p)
-    worst, steps, st_valid = (0.0, 0.0), [], 0
+    with glp.gl.transcendentals("detmath"):
+        k6 = glp.gl.Jacobians(p)
+    steps = []
     for k in range(5):
         pts, lab, prob, _ = get_scan(k, W, True)
         if k >= 1:
@@ -59,24 +63,21 @@ def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
             pp = params_with_size(W, max_iterations=ITER, stopping_threshold=0.0, delta=0.0)
             ora.set_params(pp)
             _, hist, st = ora.minimize(cur, model, op.last_increment(), history_cap=ITER + 1)
-            st_valid = st.valid
             ora.set_params(p)
             assert hist.shape[0] == ITER + 1
             cm, mm = [cur.map(m) for m in range(3)], [model.map(m) for m in range(3)]
             for it in range(ITER):
-                b = g.k6.run(cm, mm, hist[it], it)
+                b = k6.run(cm, mm, hist[it], it)
                 dx = np.linalg.solve(b[:36].reshape(6, 6).astype(np.float64), -b[36:42].astype(np.float64))
                 Tn = glp.pyref.se3_exp(dx) @ hist[it]
-                dt, dr = pose_delta(Tn, hist[it + 1])
-                worst = (max(worst[0], dt), max(worst[1], dr))
-                steps.append((k, it, dt, dr, st_valid))
+                steps.append((k, it) + pose_delta(Tn, hist[it + 1]) + (st.valid,))
         op.process_scan(pts, lab, prob, fixed_iterations=ITER)
     for row in steps:
         print("scan %d it %d: %.2e m %.2e rad (%d pairs)" % row)
     dts, drs = np.array([r[2] for r in steps]), np.array([r[3] for r in steps])
-    assert dts.max() <= 2e-3 and drs.max() <= 3e-4, (dts.max(), drs.max())
-    assert np.median(dts) <= 3e-4 and np.median(drs) <= 5e-5, (np.median(dts), np.median(drs))
-    print(f"per-iteration GL vs oracle, worst of {len(steps)} steps: {worst[0]:.2e} m / {worst[1]:.2e} rad")
+    assert len(steps) == 40
+    assert dts.max() <= 1e-4 and drs.max() <= 1e-5, (dts.max(), drs.max())
+    print(f"per-iteration GL vs oracle, worst of {len(steps)} steps: {dts.max():.2e} m / {drs.max():.2e} rad")
 
 
 def test_free_running_gl_pipeline_against_the_oracle(glp, oracle_lib):
