@@ -214,6 +214,7 @@ class LieGaussNewton {
      * SurfelMapping.cpp:391): the minimisation costs the host one poll of a pinned record, no copy */
     check(ctx_.get(), suma_icp_minimize(ctx_.get(), T0, pose_, nullptr, 0, &n_hist_, &stats_), "LieGaussNewton::minimize");
     history_valid_ = false;
+    history_seq_ = suma_icp_history_sequence(ctx_.get());
     std::memcpy(F.pose_, pose_, sizeof(pose_));
     F.stats_ = stats_;
     F.iteration_ = stats_.iterations;
@@ -233,6 +234,11 @@ class LieGaussNewton {
   /* 16 doubles per entry; fetched from the device on first use after a minimisation */
   const std::vector<double>& history() {
     if (!history_valid_) {
+      /* one history buffer per context: another optimizer object (or a loop-closure verification) that has minimised
+       * since would be read here instead of this object's chain */
+      if (suma_icp_history_sequence(ctx_.get()) != history_seq_)
+        throw std::runtime_error("LieGaussNewton::history: a later minimisation on this context has overwritten the "
+                                 "device-side history; call history() before it");
       const uint32_t n = n_hist_ < 1025 ? n_hist_ : 1025;
       history_.assign(16 * (size_t)n, 0.0);
       if (n) check(ctx_.get(), suma_icp_history(ctx_.get(), history_.data(), n, nullptr), "LieGaussNewton::history");
@@ -249,6 +255,7 @@ class LieGaussNewton {
   std::vector<double> history_;
   uint32_t n_hist_{0};
   bool history_valid_{true};
+  uint64_t history_seq_{0};
   suma_icp_stats stats_;
 };
 

@@ -8,9 +8,10 @@
  * implementations flips integer outputs (pixel assignment, surfel counts).  To make "bit-exact
  * surfel indices/counts" a testable property between the CPU oracle and the gfx950 kernels,
  * the transcendental functions are part of the *specification*: both sides evaluate the very
- * same sequence of IEEE-754 binary32 +,-,*,/,sqrt operations (no FMA contraction: every
- * translation unit including this header is compiled with -ffp-contract=off; hipcc's default
- * correctly rounded fp32 divide/sqrt is relied upon and checked by tests/test_detmath.py).
+ * same sequence of IEEE-754 binary32 +,-,*,/,sqrt,fma operations (no FMA CONTRACTION: every
+ * translation unit including this header is compiled with -ffp-contract=off, the fused steps
+ * below are explicit; hipcc's default correctly rounded fp32 divide/sqrt is relied upon and
+ * checked by tests/test_detmath.py).
  *
  * Algorithms: classic Cephes single-precision kernels (S. Moshier, public domain algorithms:
  * atanf/asinf/sinf/expf/logf range reductions + minimax polynomials), restated here.
@@ -30,15 +31,16 @@
 #define SUMA_HD static inline
 #endif
 
-/* One multiply-add step of a polynomial kernel.  The SPECIFICATION is the unfused form -- two roundings, (a * b) + c --
- * on every side (oracle, compiled reference shaders, gfx950 kernels).  -DSUMA_DETMATH_FMA builds the fused form for the
- * timing experiment of round 4 only (tools/build_variant.sh: what would explicit fmaf steps inside these kernels buy?
- * DESIGN.md section 4): such a build is NOT bit-compatible with the oracle and is never shipped. */
-#ifdef SUMA_DETMATH_FMA
+/* One multiply-add step of a polynomial kernel: FUSED, a * b + c with one rounding (round 5; rounds 1-4 specified the
+ * unfused form).  The arithmetic specification of this repository is a choice -- GLSL leaves the evaluation of its
+ * built-in functions to the implementation, and a real GL (Mesa llvmpipe) was measured to differ from any fixed choice
+ * in 1-2 % of the texels through its own asin alone -- so it is chosen where the target is
+ * fastest: v_fma_f32 is one instruction on gfx950, mul + add are two (profiles/r05_spec_v2_experiment.txt: +3.2 %
+ * scans/s for the whole change).  Fused multiply-adds appear ONLY where they are written out (here, and in the vector /
+ * matrix helpers of oracle/o_math.h, oracle/glsl_compat.hpp and csrc/dev_math.h); every translation unit is still
+ * compiled with -ffp-contract=off, so the compiler forms none of its own.  On the host __builtin_fmaf is the
+ * correctly rounded fma (vfmadd with -mfma, glibc's fmaf otherwise): the same bits as the device's. */
 #define SDM_MA(a, b, c) __builtin_fmaf((a), (b), (c))
-#else
-#define SDM_MA(a, b, c) (((a) * (b)) + (c))
-#endif
 
 #define SUMA_PI_F 3.14159265358979323846f
 #define SUMA_PI_2_F 1.57079632679489661923f

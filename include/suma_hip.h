@@ -125,6 +125,11 @@ int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], doub
  * records it, the copy is only paid by callers that look at it (the reference's caller keeps it for drawing,
  * SurfelMapping.cpp:391).  *n_hist = entries the minimisation pushed; min(that, history_cap) x 16 doubles are copied. */
 int suma_icp_history(suma_ctx* ctx, double* history, uint32_t history_cap, uint32_t* n_hist);
+/* The history lives in ONE device buffer per context; every minimisation that records one (suma_icp_minimize, also inside
+ * suma_loop_closure_verify / _track) overwrites it and advances this counter.  The reference keeps history_ per optimizer
+ * object (LieGaussNewton.h:72): an adapter object notes the counter after ITS minimisation and refuses to hand out
+ * another chain's poses when it has moved (include/suma_adapter.hpp, LieGaussNewton::history). */
+uint64_t suma_icp_history_sequence(const suma_ctx* ctx);
 /* LieGaussNewton::information() (LieGaussNewton.h:50, LieGaussNewton.cpp:75,103-105): J^T W J of the last step of the
  * last suma_icp_minimize (or of the last suma_icp_jacobian_products), 6x6 column-major */
 int suma_icp_information(suma_ctx* ctx, double information[36]);

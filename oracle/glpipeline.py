@@ -32,6 +32,7 @@ class GLPipeline:
     def __init__(self, params):
         p = self.p = params
         self.W, self.H = p.data_width, p.data_height
+        self.prelude = gl._prelude[0]  # the transcendentals the programs are built with (gl.transcendentals), kept for the lazy ones
         self.ref = pyref.Ref(p)  # the uniform tables (values as the reference's host code computes them) + SE3::exp
         self.k1, self.k23 = gl.VertexMap(p), gl.NormalsLabels(p)
         self.k4, self.k6 = gl.SurfelRenderer(p), gl.Jacobians(p)
@@ -146,7 +147,11 @@ class GLPipeline:
                     import copy
                     pf = copy.copy(p)
                     pf.icp_max_distance, pf.icp_max_angle = p.fallback_max_distance, p.fallback_max_angle
-                    self.k6_fallback = gl.Jacobians(pf)
+                    saved, gl._prelude[0] = gl._prelude[0], self.prelude
+                    try:
+                        self.k6_fallback = gl.Jacobians(pf)
+                    finally:
+                        gl._prelude[0] = saved
                 k6, self.k6 = self.k6, self.k6_fallback
                 increment = self.minimize(frame, self.last_frame, self.last_increment, iterations)
                 self.k6 = k6

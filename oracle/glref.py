@@ -104,22 +104,28 @@ def available():
 # --- the CONTROL of tests/test_gl_pipeline.py: the reference's shader text with the driver's transcendentals replaced.
 # GLSL leaves the accuracy of asin / acos / atan to the implementation (GLSL 4.50 section 4.7.1: "undefined" for the
 # angle functions); llvmpipe's asin is off by up to 3.9e-4 rad.  This prelude -- the Cephes
-# kernels of include/suma_detmath.h (sdm_atan :79-99, sdm_atan2 :102-117, sdm_asin :124-148, sdm_acos :150-155) restated
-# in GLSL, one IEEE operation per statement, `precise` so that the GLSL compiler neither fuses nor reassociates -- is put
+# kernels of include/suma_detmath.h (sdm_atan, sdm_atan2, sdm_asin, sdm_acos) restated in GLSL, one IEEE operation per
+# statement -- a fused multiply-add where the header's SDM_MA is (through double: llvmpipe's own fma() rounds twice),
+# `precise` so that the GLSL compiler neither fuses nor reassociates the rest; tests/test_gl_controls.py checks the
+# functions' bits on 200 000 arguments -- is put
 # between the #version line and the reference's text, followed by three #defines.  Not one character of the reference's
 # shader is changed: what changes is the library the GL implementation evaluates its three angle functions with.
 DETMATH_PRELUDE = """
+#extension GL_ARB_gpu_shader_fp64 : require
+// one rounding: the product of two floats is exact in double, the sum is rounded to 53 bits and then to 24 (llvmpipe
+// lowers GLSL's own sdm_fma() to a multiply and an add, i.e. two roundings: measured, tests/test_gl_controls.py)
+float sdm_fma(float a, float b, float c) { precise double t = double(a) * double(b); t = t + double(c); return float(t); }
 float sdm_atan1(float xx) {
   precise float x = abs(xx);
   precise float y = 0.0;
   if (x > 2.414213562373095) { y = 1.57079632679489661923; x = -(1.0 / x); }
   else if (x > 0.4142135623730950) { y = 0.78539816339744830962; precise float a = x - 1.0; precise float b = x + 1.0; x = a / b; }
   precise float z = x * x;
-  precise float p = 8.05374449538e-2 * z;
-  p = p + -1.38776856032e-1;
-  p = p * z; p = p + 1.99777106478e-1;
-  p = p * z; p = p + -3.33329491539e-1;
-  p = p * z; p = p * x; p = p + x;
+  precise float p = sdm_fma(8.05374449538e-2, z, -1.38776856032e-1);
+  p = sdm_fma(p, z, 1.99777106478e-1);
+  p = sdm_fma(p, z, -3.33329491539e-1);
+  precise float pz = p * z;
+  p = sdm_fma(pz, x, x);
   y = y + p;
   return (xx < 0.0) ? -y : y;
 }
@@ -138,11 +144,12 @@ float sdm_asin_gl(float xx) {
   if (a < 1.0e-4) return xx;
   precise float x; precise float z; bool flag = false;
   if (a > 0.5) { z = 1.0 - a; z = 0.5 * z; x = sqrt(z); flag = true; } else { x = a; z = x * x; }
-  precise float p = 4.2163199048e-2 * z; p = p + 2.4181311049e-2;
-  p = p * z; p = p + 4.5470025998e-2;
-  p = p * z; p = p + 7.4953002686e-2;
-  p = p * z; p = p + 1.6666752422e-1;
-  p = p * z; p = p * x; z = p + x;
+  precise float p = sdm_fma(4.2163199048e-2, z, 2.4181311049e-2);
+  p = sdm_fma(p, z, 4.5470025998e-2);
+  p = sdm_fma(p, z, 7.4953002686e-2);
+  p = sdm_fma(p, z, 1.6666752422e-1);
+  precise float pz = p * z;
+  z = sdm_fma(pz, x, x);
   if (flag) { z = z + z; z = 1.57079632679489661923 - z; }
   return (xx < 0.0) ? -z : z;
 }
@@ -932,6 +939,46 @@ class SurfelFilter:
             g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, rec.nbytes,
                                                                                rec.ctypes.data)
         return rec.reshape(-1, 16)
+
+
+def eval_vertex_shader(vs_text, attribs, out_components, out_name="r", prelude="driver"):
+    """run an OWN one-stage shader over arrays of float attributes and capture ONE vecN output per vertex through
+    transform feedback (rasteriser discarded): how tests look at the GL implementation's built-in functions value by
+    value.  attribs: {attribute name: float32 array}; prelude: "driver" | "detmath" (transcendentals, above)."""
+    import re
+    g = Context.get()
+    text = vs_text
+    pre = {"driver": "", "detmath": DETMATH_PRELUDE}[prelude]
+    if pre:
+        text = re.sub(r"^(\s*#version[^\n]*\n)", lambda m: m.group(1) + "#extension GL_ARB_gpu_shader5 : require\n" + pre, text, count=1)
+    prog = Program({"VERTEX_SHADER": text}, tf_varyings=[out_name], from_reference=False)
+    n = len(next(iter(attribs.values())))
+    vao = gen("VertexArrays")
+    g.fn("glBindVertexArray", None, u32)(vao)
+    keep = []
+    for name, arr in attribs.items():
+        loc = g.fn("glGetAttribLocation", i32, u32, C.c_char_p)(prog.id, name.encode())
+        if loc < 0:
+            continue
+        b = Buffer(np.ascontiguousarray(arr, dtype=np.float32))
+        keep.append(b)
+        g.fn("glBindBuffer", None, u32, u32)(GL["ARRAY_BUFFER"], b.id)
+        g.fn("glVertexAttribPointer", None, u32, i32, u32, C.c_ubyte, i32, vp)(loc, 1, GL["FLOAT"], 0, 4, 0)
+        g.fn("glEnableVertexAttribArray", None, u32)(loc)
+    out = Buffer(nbytes=max(n, 1) * 4 * out_components)
+    g.fn("glBindBufferBase", None, u32, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, out.id)
+    prog.use()
+    g.fn("glEnable", None, u32)(GL["RASTERIZER_DISCARD"])
+    g.fn("glBeginTransformFeedback", None, u32)(GL["POINTS"])
+    draw_points(vao, n)
+    g.fn("glEndTransformFeedback", None)()
+    g.fn("glDisable", None, u32)(GL["RASTERIZER_DISCARD"])
+    g.fn("glFinish", None)()
+    g.check("eval_vertex_shader")
+    res = np.empty(n * out_components, dtype=np.float32)
+    g.fn("glBindBuffer", None, u32, u32)(GL["TRANSFORM_FEEDBACK_BUFFER"], out.id)
+    g.fn("glGetBufferSubData", None, u32, C.c_ssize_t, C.c_ssize_t, vp)(GL["TRANSFORM_FEEDBACK_BUFFER"], 0, res.nbytes, res.ctypes.data)
+    return res.reshape(n, out_components)
 
 
 def _map_sampler():

@@ -11,8 +11,10 @@
  *   operators, the built-in functions the hot-path shaders call, and rectangle / buffer samplers with
  *   NEAREST / LINEAR filtering and CLAMP_TO_BORDER (border colour 0), GL 3.3 core spec 3.8.
  * Every operation is IEEE binary32 in the natural left-to-right order of the GLSL specification's formulas
- * (dot = x*x' + y*y' + z*z', normalize = v / length(v), mat*vec = sum of column * component), compiled with
- * -ffp-contract=off.  Transcendental functions are a build switch: REF_USE_LIBM selects glibc's, otherwise the
+ * (dot = x*x' + y*y' + z*z', normalize = v / length(v), mat*vec = sum of column * component); since round 5 the sums
+ * of products INSIDE the built-ins are explicit fused multiply-add chains and vector / scalar multiplies by one
+ * correctly rounded reciprocal (what a GPU's GLSL compiler emits; the arithmetic of the shader TEXT stays unfused:
+ * compiled with -ffp-contract=off).  Transcendental functions are a build switch: REF_USE_LIBM selects glibc's, otherwise the
  * repository's deterministic ones (include/suma_detmath.h) -- GL leaves their last bits to the driver.
  */
 #ifndef ORACLE_GLSL_COMPAT_HPP_
@@ -298,8 +300,22 @@ inline typename std::enable_if<(vt<T>::n > 0), R>::type bc(const T& v) {
 GLSL_BINOP(+)
 GLSL_BINOP(-)
 GLSL_BINOP(*)
-GLSL_BINOP(/)
 #undef GLSL_BINOP
+/* operator/ : vector / SCALAR is a multiplication by ONE correctly rounded reciprocal (round 5: what a GPU's GLSL
+ * compiler emits for it -- v * rcp(s) -- with the rcp exact; oracle/o_math.h ov3_divs and csrc/dev_math.h divs3 are the
+ * same three operations); vector / vector and scalar / vector divide component by component */
+template <class A, class B>
+inline binres_t<A, B> operator/(const A& a, const B& b) {
+  typedef binres_t<A, B> R;
+  R x = bc<R>(a), y = bc<R>(b), r;
+  if (vt<A>::n > 0 && std::is_arithmetic<B>::value) {
+    const float rcp = 1.0f / y[0];
+    for (int i = 0; i < R::N; ++i) r[i] = x[i] * rcp;
+  } else {
+    for (int i = 0; i < R::N; ++i) r[i] = x[i] / y[i];
+  }
+  return r;
+}
 template <class A>
 inline unres_t<A> operator-(const A& a) {
   typedef unres_t<A> R;
@@ -373,9 +389,12 @@ inline float degrees(float r) { return r * 57.295779513082320877f; }
 inline float radians(float d) { return d * 0.017453292519943295769f; }
 
 /* ---- vector built-ins ---- */
-inline float dot(const vec2& a, const vec2& b) { return a.x * b.x + a.y * b.y; }
-inline float dot(const vec3& a, const vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-inline float dot(const vec4& a, const vec4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+/* sums of products inside the built-ins: chains of explicit fused multiply-adds in component order (round 5,
+ * include/suma_detmath.h SDM_MA; the compiler forms none of its own: -ffp-contract=off) */
+inline float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+inline float dot(const vec2& a, const vec2& b) { return fma_(a.y, b.y, a.x * b.x); }
+inline float dot(const vec3& a, const vec3& b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+inline float dot(const vec4& a, const vec4& b) { return fma_(a.w, b.w, fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x))); }
 inline float length(const vec2& a) { return sqrt(dot(a, a)); }
 inline float length(const vec3& a) { return sqrt(dot(a, a)); }
 inline float length(const vec4& a) { return sqrt(dot(a, a)); }
@@ -385,7 +404,8 @@ inline vec3 normalize(const vec3& a) { return a / length(a); }
 inline vec4 normalize(const vec4& a) { return a / length(a); }
 inline float distance(const vec3& a, const vec3& b) { return length(a - b); }
 inline vec3 cross(const vec3& a, const vec3& b) {
-  return vec3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); /* GLSL spec 8.5 */
+  /* GLSL spec 8.5: x[1] y[2] - y[1] x[2], ...; the first product fused into the subtraction */
+  return vec3(fma_(a.y, b.z, -(b.y * a.z)), fma_(a.z, b.x, -(b.z * a.x)), fma_(a.x, b.y, -(b.x * a.y)));
 }
 #define GLSL_MAP1(F)                                                   \
   inline vec2 F(const vec2& a) { return vec2(F(a.x), F(a.y)); }        \
@@ -451,9 +471,17 @@ inline mat3::mat3(const mat4& m) {
   c[1] = vec3(m.c[1]);
   c[2] = vec3(m.c[2]);
 }
-/* linear-algebraic products, summed in column order */
-inline vec4 operator*(const mat4& m, const vec4& v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z + m.c[3] * v.w; }
-inline vec3 operator*(const mat3& m, const vec3& v) { return m.c[0] * v.x + m.c[1] * v.y + m.c[2] * v.z; }
+/* linear-algebraic products, accumulated in column order with fused multiply-adds: fma(c3, w, fma(c2, z, fma(c1, y, c0 x))) */
+inline vec4 operator*(const mat4& m, const vec4& v) {
+  vec4 r;
+  for (int i = 0; i < 4; ++i) r[i] = fma_(m.c[3][i], v.w, fma_(m.c[2][i], v.z, fma_(m.c[1][i], v.y, m.c[0][i] * v.x)));
+  return r;
+}
+inline vec3 operator*(const mat3& m, const vec3& v) {
+  vec3 r;
+  for (int i = 0; i < 3; ++i) r[i] = fma_(m.c[2][i], v.z, fma_(m.c[1][i], v.y, m.c[0][i] * v.x));
+  return r;
+}
 inline mat4 operator*(const mat4& a, const mat4& b) { return mat4(a * b.c[0], a * b.c[1], a * b.c[2], a * b.c[3]); }
 inline mat3 operator*(const mat3& a, const mat3& b) { return mat3(a * b.c[0], a * b.c[1], a * b.c[2]); }
 inline mat3 operator-(const mat3& a) { return mat3(-a.c[0], -a.c[1], -a.c[2]); }

@@ -5,6 +5,12 @@
  * the reference's shaders use (dot, cross, length, normalize, mat4*vec4, mat4*mat4).  The
  * operation order below IS the specification; the gfx950 kernels restate the same order so the
  * two can be compared bit for bit.  Compiled with -ffp-contract=off.
+ *
+ * Round 5: the sums of products inside these built-ins are chains of EXPLICIT fused multiply-adds
+ * (dot = fma(z, z', fma(y, y', x * x')), mat * vec = fma over the columns in order), and vector / scalar
+ * is three multiplies by ONE correctly rounded reciprocal -- the forms a GPU's GLSL compiler
+ * emits, and the fastest on gfx950 (include/suma_detmath.h, SDM_MA).  Statements of the shaders
+ * themselves (a * b + c written out in the shader text) stay unfused.
  */
 #ifndef ORACLE_O_MATH_H_
 #define ORACLE_O_MATH_H_
@@ -37,42 +43,46 @@ static inline ov3 ov3_make(float x, float y, float z) {
   ov3 r = {x, y, z};
   return r;
 }
-static inline float ov3_dot(ov3 a, ov3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+#define O_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+static inline float ov3_dot(ov3 a, ov3 b) { return O_FMA(a.z, b.z, O_FMA(a.y, b.y, a.x * b.x)); }
 static inline float ov3_len(ov3 a) { return sdm_sqrt(ov3_dot(a, a)); }
 static inline ov3 ov3_sub(ov3 a, ov3 b) { return ov3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
 static inline ov3 ov3_add(ov3 a, ov3 b) { return ov3_make(a.x + b.x, a.y + b.y, a.z + b.z); }
 static inline ov3 ov3_scale(float s, ov3 a) { return ov3_make(s * a.x, s * a.y, s * a.z); }
-static inline ov3 ov3_divs(ov3 a, float s) { return ov3_make(a.x / s, a.y / s, a.z / s); }
+/* GLSL vec / float: one correctly rounded reciprocal, three multiplies */
+static inline ov3 ov3_divs(ov3 a, float s) {
+  const float r = 1.0f / s;
+  return ov3_make(a.x * r, a.y * r, a.z * r);
+}
 static inline ov3 ov3_neg(ov3 a) { return ov3_make(-a.x, -a.y, -a.z); }
 /* GLSL normalize(): v / length(v) */
 static inline ov3 ov3_normalize(ov3 a) { return ov3_divs(a, ov3_len(a)); }
 static inline ov3 ov3_cross(ov3 a, ov3 b) {
-  return ov3_make(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+  return ov3_make(O_FMA(a.y, b.z, -(a.z * b.y)), O_FMA(a.z, b.x, -(a.x * b.z)), O_FMA(a.x, b.y, -(a.y * b.x)));
 }
 
 /* column-major 4x4 (Eigen::Matrix4f / GLSL mat4): element (row r, col c) = m[4*c + r] */
-/* M * (p, 1) : ((col0*x + col1*y) + col2*z) + col3, xyz rows only */
+/* M * (p, 1) : fma(col2, z, fma(col1, y, col0 * x)) + col3 (= fma(col3, 1, .)), xyz rows only */
 static inline ov3 om4_point(const float* m, ov3 p) {
   ov3 r;
-  r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12];
-  r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13];
-  r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14];
+  r.x = O_FMA(m[8], p.z, O_FMA(m[4], p.y, m[0] * p.x)) + m[12];
+  r.y = O_FMA(m[9], p.z, O_FMA(m[5], p.y, m[1] * p.x)) + m[13];
+  r.z = O_FMA(m[10], p.z, O_FMA(m[6], p.y, m[2] * p.x)) + m[14];
   return r;
 }
 /* M * (d, 0) */
 static inline ov3 om4_dir(const float* m, ov3 d) {
   ov3 r;
-  r.x = (m[0] * d.x + m[4] * d.y) + m[8] * d.z;
-  r.y = (m[1] * d.x + m[5] * d.y) + m[9] * d.z;
-  r.z = (m[2] * d.x + m[6] * d.y) + m[10] * d.z;
+  r.x = O_FMA(m[8], d.z, O_FMA(m[4], d.y, m[0] * d.x));
+  r.y = O_FMA(m[9], d.z, O_FMA(m[5], d.y, m[1] * d.x));
+  r.z = O_FMA(m[10], d.z, O_FMA(m[6], d.y, m[2] * d.x));
   return r;
 }
-/* C = A * B, each element ((a0*b0 + a1*b1) + a2*b2) + a3*b3 */
+/* C = A * B, each element fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0))) */
 static inline void om4_mul(const float* A, const float* B, float* C) {
   for (int c = 0; c < 4; ++c)
     for (int r = 0; r < 4; ++r)
-      C[4 * c + r] =
-          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+      C[4 * c + r] = O_FMA(A[12 + r], B[4 * c + 3], O_FMA(A[8 + r], B[4 * c + 2], O_FMA(A[4 + r], B[4 * c + 1], A[r] * B[4 * c])));
 }
 /* Inverse of a rigid transform, evaluated in double from the fp32 matrix and rounded once to
  * fp32: R^T, -R^T t.  (The reference uses Eigen's / GLSL's general inverse on rigid poses,

@@ -114,7 +114,8 @@ static void o_k2_normals(const ora_ctx* c, const ora_frame* f, suma_float4* norm
         if (nrm.w > 0.0f) {
           ov3 w = ov3_cross(un, vn);
           float len = ov3_len(w);
-          nrm = o_f4(w.x / len, w.y / len, w.z / len, (len > 0.0000001f) ? 1.0f : 0.0f);
+          const ov3 wn = ov3_divs(w, len); /* vec3 / float */
+          nrm = o_f4(wn.x, wn.y, wn.z, (len > 0.0000001f) ? 1.0f : 0.0f);
         }
       }
       normal[pix] = nrm;
@@ -227,7 +228,10 @@ static void o_k1b_average(const ora_ctx* c, const suma_float4* vsum, suma_float4
   for (int32_t y = 0; y < H; ++y)
     for (int32_t x = 0; x < W; ++x) {
       suma_float4 v = o_filter_fetch(c, vsum, o_filter_coord(x, W), o_filter_coord(y, H));
-      if (v.w > 0.5f) v = o_f4(v.x / v.w, v.y / v.w, v.z / v.w, v.w / v.w);
+      if (v.w > 0.5f) { /* vec4 / float: one reciprocal, four multiplies (o_math.h) */
+        const float rw = 1.0f / v.w;
+        v = o_f4(v.x * rw, v.y * rw, v.z * rw, v.w * rw);
+      }
       out[(size_t)y * W + x] = v;
     }
 }
@@ -260,7 +264,8 @@ static void o_k1c_bilateral(const ora_ctx* c, const suma_float4* V, suma_float4*
             while (xx < 0.0f) xx = xx + width;
             suma_float4 tmp = o_filter_fetch(c, V, (int32_t)xx, cy);
             if (tmp.w < 0.5f) continue;
-            float tmp_range = sdm_sqrt(((tmp.x * tmp.x + tmp.y * tmp.y) + tmp.z * tmp.z) + tmp.w * tmp.w);
+            /* length(vec4) = sqrt(dot): the fused chain of o_math.h over four components */
+            float tmp_range = sdm_sqrt(O_FMA(tmp.w, tmp.w, O_FMA(tmp.z, tmp.z, O_FMA(tmp.y, tmp.y, tmp.x * tmp.x))));
             float dx = (float)x - xx;
             float diff_space2 = dx * dx + (float)((y - cy) * (y - cy));
             float diff_range2 = (range - tmp_range) * (range - tmp_range);

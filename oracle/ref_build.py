@@ -166,7 +166,8 @@ def main():
         f.write("  {nullptr, nullptr, 0, nullptr}};\n}  // namespace glsl\n")
 
     cxx = os.environ.get("CXX", "g++")
-    flags = ["-O2", "-std=gnu++14", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing",
+    fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []  # explicit fmas inline (the same bits as glibc's fmaf)
+    flags = ["-O2", "-std=gnu++14", "-fPIC", "-shared", "-w", "-ffp-contract=off", "-fno-fast-math", "-fno-strict-aliasing", *fma,
              "-I", OUT, "-I", HERE, "-I", os.path.join(HERE, "eigen_shim"), "-I", os.path.join(src_root, "core"),
              "-I", src_root]
     srcs = [os.path.join(HERE, "ref_driver.cpp"), os.path.join(src_root, "core", "lie_algebra.cpp")]

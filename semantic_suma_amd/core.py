@@ -131,6 +131,8 @@ def lib():
     L.suma_icp_jacobian_products.argtypes = [vp, vp, u32, vp, vp, vp, C.POINTER(IcpStats)]
     L.suma_icp_minimize.argtypes = [vp, vp, vp, vp, u32, C.POINTER(u32), C.POINTER(IcpStats)]
     L.suma_icp_history.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.suma_icp_history_sequence.argtypes = [vp]
+    L.suma_icp_history_sequence.restype = C.c_uint64
     L.suma_frame_touch.argtypes = [vp, vp]
     L.suma_pipeline_minimize_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_icp_minimize_batch.argtypes = [vp, vp, u32, vp, vp]
@@ -471,6 +473,7 @@ class LieGaussNewton:
         objective._pose = self._pose
         objective.stats = self.stats
         self._history, self._history_cap = None, history_cap
+        self._history_seq = c.L.suma_icp_history_sequence(c.h)
         return 0
 
     def minimize_batch(self, T0s, objective: Frame2Model = None):
@@ -490,6 +493,9 @@ class LieGaussNewton:
 
     def history(self):
         if self._history is None:
+            if self.ctx.L.suma_icp_history_sequence(self.ctx.h) != self._history_seq:
+                raise RuntimeError("LieGaussNewton.history: a later minimisation on this context has overwritten the "
+                                   "device-side history; call history() before it")
             cap = self._history_cap
             hist = np.zeros((max(cap, 1), 4, 4), dtype=np.float64)
             nh = C.c_uint32(0)

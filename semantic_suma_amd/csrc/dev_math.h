@@ -3,10 +3,10 @@
  *
  * The projective pipeline turns floats into pixel indices through floor(), so the ORDER of the
  * fp32 operations is part of the specification (DESIGN.md "Determinism"): every expression below
- * is written as an explicit sequence of IEEE binary32 +,-,*,/,sqrt with the association the
+ * is written as an explicit sequence of IEEE binary32 +,-,*,/,sqrt,fma with the association the
  * reference's GLSL built-ins imply (dot, cross, length, normalize, mat4*vec4, mat4*mat4;
  * e.g. src/shader/gen_vertexmap.vert:73-103).  All translation units are compiled with
- * -ffp-contract=off so no FMA is formed; hipcc's fp32 divide / sqrt are correctly rounded.
+ * -ffp-contract=off so the compiler forms no FMA of its own; hipcc's fp32 divide / sqrt are correctly rounded.
  * Transcendentals come from include/suma_detmath.h.
  */
 #ifndef SUMA_DEV_MATH_H_
@@ -32,46 +32,55 @@ SDEV v3 mk3(float x, float y, float z) {
   return r;
 }
 SDEV v3 xyz(const float4& a) { return mk3(a.x, a.y, a.z); }
-SDEV float dot3(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+/* Round 5: the sums of products inside the GLSL built-ins are chains of EXPLICIT fused multiply-adds (v_fma_f32: one
+ * instruction where mul + add are two), and vector / scalar is three multiplies by ONE correctly rounded reciprocal --
+ * the same operations, in the same order, as the CPU checker and the compiled reference shaders use (profiles/r05_spec_v2_experiment.txt:
+ * -7 ... -21 % VALU instructions in the map kernels, +3.2 % scans/s).  The compiler still forms no fma of its own. */
+#define SDEV_FMA(a, b, c) __builtin_fmaf((a), (b), (c))
+SDEV float dot3(v3 a, v3 b) { return SDEV_FMA(a.z, b.z, SDEV_FMA(a.y, b.y, a.x * b.x)); }
 SDEV float len3(v3 a) { return sdm_sqrt(dot3(a, a)); }
 SDEV v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
 SDEV v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
 SDEV v3 scale3(float s, v3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
-SDEV v3 divs3(v3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+/* GLSL vec / float */
+SDEV v3 divs3(v3 a, float s) {
+  const float r = 1.0f / s;
+  return mk3(a.x * r, a.y * r, a.z * r);
+}
 SDEV v3 neg3(v3 a) { return mk3(-a.x, -a.y, -a.z); }
 SDEV v3 normalize3(v3 a) { return divs3(a, len3(a)); } /* GLSL normalize(): v / length(v) */
-SDEV v3 cross3(v3 a, v3 b) { return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+SDEV v3 cross3(v3 a, v3 b) {
+  return mk3(SDEV_FMA(a.y, b.z, -(a.z * b.y)), SDEV_FMA(a.z, b.x, -(a.x * b.z)), SDEV_FMA(a.x, b.y, -(a.y * b.x)));
+}
 
 /* column-major 4x4 by value (kernel argument / register resident) */
 struct m4 {
   float m[16];
 };
 
-/* M * (p, 1): ((col0*x + col1*y) + col2*z) + col3 */
+/* M * (p, 1): fma(col2, z, fma(col1, y, col0 * x)) + col3 */
 SDEV v3 m4_point(const float* m, v3 p) {
   v3 r;
-  r.x = ((m[0] * p.x + m[4] * p.y) + m[8] * p.z) + m[12];
-  r.y = ((m[1] * p.x + m[5] * p.y) + m[9] * p.z) + m[13];
-  r.z = ((m[2] * p.x + m[6] * p.y) + m[10] * p.z) + m[14];
+  r.x = SDEV_FMA(m[8], p.z, SDEV_FMA(m[4], p.y, m[0] * p.x)) + m[12];
+  r.y = SDEV_FMA(m[9], p.z, SDEV_FMA(m[5], p.y, m[1] * p.x)) + m[13];
+  r.z = SDEV_FMA(m[10], p.z, SDEV_FMA(m[6], p.y, m[2] * p.x)) + m[14];
   return r;
 }
 /* M * (d, 0) */
 SDEV v3 m4_dir(const float* m, v3 d) {
   v3 r;
-  r.x = (m[0] * d.x + m[4] * d.y) + m[8] * d.z;
-  r.y = (m[1] * d.x + m[5] * d.y) + m[9] * d.z;
-  r.z = (m[2] * d.x + m[6] * d.y) + m[10] * d.z;
+  r.x = SDEV_FMA(m[8], d.z, SDEV_FMA(m[4], d.y, m[0] * d.x));
+  r.y = SDEV_FMA(m[9], d.z, SDEV_FMA(m[5], d.y, m[1] * d.x));
+  r.z = SDEV_FMA(m[10], d.z, SDEV_FMA(m[6], d.y, m[2] * d.x));
   return r;
 }
-/* upper 3x4 of C = A * B for rigid A, B (bottom row 0,0,0,1 is implied and exact):
- * each element ((a0*b0 + a1*b1) + a2*b2) + a3*b3 with b3 in {0, 1} */
+/* C = A * B: each element fma(a3, b3, fma(a2, b2, fma(a1, b1, a0 * b0))) */
 SDEV void m4_mul(const float* A, const float* B, float* C) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      C[4 * c + r] =
-          ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
+      C[4 * c + r] = SDEV_FMA(A[12 + r], B[4 * c + 3], SDEV_FMA(A[8 + r], B[4 * c + 2], SDEV_FMA(A[4 + r], B[4 * c + 1], A[r] * B[4 * c])));
   }
 }
 

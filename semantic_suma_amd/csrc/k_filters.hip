@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(256)
   if (pix >= (uint32_t)W * (uint32_t)H) return;
   const int32_t y = (int32_t)(pix / (uint32_t)W), x = (int32_t)(pix - (uint32_t)y * (uint32_t)W);
   float4 v = filter_fetch(vsum, W, x, y, nearest);
-  if (v.w > 0.5f) v = f4(v.x / v.w, v.y / v.w, v.z / v.w, v.w / v.w);
+  if (v.w > 0.5f) { /* vec4 / float: one reciprocal, four multiplies (dev_math.h divs3) */
+    const float rw = 1.0f / v.w;
+    v = f4(v.x * rw, v.y * rw, v.z * rw, v.w * rw);
+  }
   out[pix] = v;
 }
 
@@ -151,7 +154,8 @@ __global__ void __launch_bounds__(BF_TX* BF_TY)
         const float xx = bf_wrap((float)cx, width);
         const float4 tmp = sT[cy - y0 + BF_R][cx - x0 + BF_R];
         if (tmp.w < 0.5f) continue;
-        const float tmp_range = sdm_sqrt(((tmp.x * tmp.x + tmp.y * tmp.y) + tmp.z * tmp.z) + tmp.w * tmp.w);
+        /* length(vec4) = sqrt(dot): the fused chain of dev_math.h over four components */
+        const float tmp_range = sdm_sqrt(SDEV_FMA(tmp.w, tmp.w, SDEV_FMA(tmp.z, tmp.z, SDEV_FMA(tmp.y, tmp.y, tmp.x * tmp.x))));
         const float dx = (float)x - xx;
         const float diff_space2 = dx * dx + (float)((y - cy) * (y - cy));
         const float diff_range2 = (range - tmp_range) * (range - tmp_range);

@@ -392,8 +392,21 @@ struct IterArgs {
  *             (LieGaussNewton::step, LieGaussNewton.cpp:53-79).  Done by every block on its own
  *             copy (identical inputs, identical code => identical results); block 0 records it.
  *   body:     unless finished, the K6 pixel phase at the current pose -> one partial per block. */
+/* The two 4 x 4 double matrices of IterArgs (T0: the start pose of a fresh chain; pose_base: the sensor pose the closing
+ * launch multiplies the increment onto) are 64 SGPRs that almost no launch needs: held for the whole kernel they pushed
+ * the one-wave consume step of k_icp_finish over the 102 SGPRs of a wave -- 47 spilled, 118 v_readlane in a serial
+ * chain (tools/isa_stats.py).  They are read from the kernel-argument segment at their one use instead (scalar loads;
+ * the empty asm keeps them there).  karg_off = offset of the IterArgs parameter in the segment. */
+typedef const IterArgs __attribute__((address_space(4))) * IterArgsK;
+__device__ __forceinline__ IterArgsK gn_args_again(uint32_t karg_off) {
+  const char __attribute__((address_space(4)))* p =
+      (const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + karg_off;
+  asm volatile("" : "+s"(p));
+  return (IterArgsK)p;
+}
+
 template <bool PIXEL>
-__device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
+__device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t karg_off) {
   const IcpArgs& a = g.a;
   const GnState* __restrict__ gin = g.gin + blockIdx.y;
   GnState* __restrict__ gout = g.gout + blockIdx.y;
@@ -442,8 +455,14 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
   const uint32_t done_in = g.init ? 0u : gin->done, pending = g.init ? 0u : gin->pending;
   uint32_t iteration = g.init ? g.iteration0 : gin->iteration;
   double Tk[16];
+  if (g.init) {
+    const IterArgsK gk = gn_args_again(karg_off);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) Tk[i] = g.init ? g.T0.m[i] : gin->Tk[i];
+    for (int i = 0; i < 16; ++i) Tk[i] = gk->T0.m[i];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) Tk[i] = gin->Tk[i];
+  }
   const bool want_px = PIXEL && !(done_in && !pending);
 
   float prefetch_sink = 0.0f;
@@ -641,7 +660,10 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g) {
       gout->pending = 0;
       if (!PIXEL && g.emit_pose && blockIdx.y == 0) {
         double Pd[16];
-        mul4d(g.pose_base.m, Tk, Pd); /* currentPose_new_ * increment, in double as on the host */
+        double base[16];
+        const IterArgsK gk = gn_args_again(karg_off);
+        for (int i = 0; i < 16; ++i) base[i] = gk->pose_base.m[i];
+        mul4d(base, Tk, Pd); /* currentPose_new_ * increment, in double as on the host */
         float Pf[16], Pinv[16];
         for (int i = 0; i < 16; ++i) Pf[i] = (float)Pd[i];
         rigid_inverse_dev(Pf, Pinv);
@@ -891,12 +913,12 @@ __global__ void __launch_bounds__(ICP_THREADS)
   g.a.Vd = Vd;
   g.a.Nd = Nd;
   g.a.Sd = Sd;
-  icp_iter_body<true>(g);
+  icp_iter_body<true>(g, 40u); /* five leading pointers, then IterArgs */
 }
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_finish(const long long* pin, const GnState* gin, IterArgs g) {
   g.pin = pin;
   g.gin = gin;
-  icp_iter_body<false>(g);
+  icp_iter_body<false>(g, 16u); /* two leading pointers, then IterArgs */
 }
 
 static IcpArgs make_args(suma_ctx* c) {

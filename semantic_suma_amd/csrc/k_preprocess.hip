@@ -147,7 +147,8 @@ __global__ void __launch_bounds__(PRE_TX* PRE_TY)
       if (nrm.w > 0.0f) {
         v3 w = cross3(un, vn);
         float len = len3(w);
-        nrm = f4(w.x / len, w.y / len, w.z / len, (len > 0.0000001f) ? 1.0f : 0.0f);
+        const v3 wn = divs3(w, len); /* vec3 / float */
+        nrm = f4(wn.x, wn.y, wn.z, (len > 0.0000001f) ? 1.0f : 0.0f);
       }
     }
     if (inside) normal[(size_t)gy * W + gx] = nrm;

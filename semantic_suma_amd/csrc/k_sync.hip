@@ -62,12 +62,12 @@ int ensure_side_stream(suma_ctx* c) {
     return SUMA_OK;
   }
   HIP_TRY(c, hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking));
+  g_side_ctxs.fetch_add(1); /* counted with the stream: side_stream_released() decrements whenever the stream exists */
   HIP_TRY(c, hipEventCreateWithFlags(&c->pre_event, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->order_event, hipEventDisableTiming));
   HIP_TRY(c, hipMalloc((void**)&c->zbuf_k1, c->P * 8));
   HIP_TRY(c, hipMemsetAsync(c->zbuf_k1, 0xFF, c->P * 8, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  g_side_ctxs.fetch_add(1);
   return SUMA_OK;
 }
 void side_stream_released(suma_ctx* c) {

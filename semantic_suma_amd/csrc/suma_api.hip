@@ -193,6 +193,9 @@ static int frame_create_raw(suma_ctx* c, uint32_t w, uint32_t h, suma_frame** ou
   }
   hipMemsetAsync(base, 0, 3 * P * sizeof(float4), c->stream);
   for (int m = 0; m < 3; ++m) f->map[m] = base + m * P;
+  /* the memset is ctx-stream work on this frame: a side-stream preprocessing into it must be ordered behind it when
+   * the ctx stream has a backlog (round-4 advisor: last_access stayed 0, so the memset could land on fresh maps) */
+  accessed(c, f);
   *out = f;
   return SUMA_OK;
 }
@@ -226,6 +229,7 @@ static int map_reset_impl(suma_ctx* c) {
   c->map_version++;
   c->rendered.valid = false;
   c->k7.valid = false;
+  c->k8_fused_frame = nullptr; /* the timestamp restarts at 0: a stale (frame, stamp) pair must not match again */
   return SUMA_OK;
 }
 
@@ -459,6 +463,13 @@ extern "C" int suma_frame_create(suma_ctx* c, uint32_t w, uint32_t h, suma_frame
 }
 extern "C" void suma_frame_destroy(suma_frame* f) {
   if (!f) return;
+  /* nothing the context remembers by frame POINTER may outlive the frame (a new frame can get the same address and,
+   * at timestamp 0, the same version: round-4 advisor) */
+  if (suma_ctx* c = f->ctx) {
+    if (c->k8_fused_frame == f) c->k8_fused_frame = nullptr;
+    if (c->gate_frame == f) c->gate_frame = nullptr;
+    if (c->rendered.out == f) c->rendered.valid = false;
+  }
   if (f->map[0]) hipFree(f->map[0]);
   delete f;
 }
@@ -505,7 +516,12 @@ extern "C" void* suma_frame_device_ptr(const suma_frame* f, int which) {
 extern "C" int suma_frame_swap(suma_ctx* c, suma_frame* a, suma_frame* b) {
   if (!c || !a || !b) return SUMA_ERR_INVALID;
   if (a->width != b->width || a->height != b->height) return fail(c, SUMA_ERR_INVALID, "suma_frame_swap: sizes differ");
+  /* the hazard bookkeeping follows the BUFFERS: a pending side-stream hand-off into either frame is flushed first, and
+   * both handles inherit the later of the two ctx-stream accesses (round-4 advisor) */
+  if (c->gate_pending && (c->gate_frame == a || c->gate_frame == b)) CK(flush_gate(c));
   for (int m = 0; m < 3; ++m) std::swap(a->map[m], b->map[m]);
+  const uint64_t la = a->last_access > b->last_access ? a->last_access : b->last_access;
+  a->last_access = b->last_access = la;
   a->version++;
   b->version++;
   return SUMA_OK;
@@ -770,6 +786,7 @@ static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int 
   if (c->gate_pending) CK(flush_gate(c)); /* the chain reads the frame the side stream preprocessed (k_sync.hip) */
   accessed(c, c->icp_current);
   accessed(c, c->icp_model);
+  if (with_history) c->hist_seq += 1; /* this chain overwrites the device-side pose history */
   CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
@@ -835,6 +852,8 @@ extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[
   if (history != nullptr && history_cap > 0) return suma_icp_history(c, history, history_cap, nullptr);
   return SUMA_OK;
 }
+
+extern "C" uint64_t suma_icp_history_sequence(const suma_ctx* c) { return c ? c->hist_seq : 0; }
 
 extern "C" int suma_icp_history(suma_ctx* c, double* history, uint32_t history_cap, uint32_t* n_hist) {
   if (!c || (!history && history_cap)) return SUMA_ERR_INVALID;

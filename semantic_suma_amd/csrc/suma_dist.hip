@@ -139,13 +139,7 @@ extern "C" int suma_gather_poses(suma_ctx* ctx, suma_dist_comm* c, const double 
 /* Element-wise sum over the ranks of a table of doubles: the exchange step of suma_run_hypotheses (include/suma_runner.h;
  * every row of the n_hyp x 18 table is owned by exactly one rank and zero elsewhere, so the sum IS the gathered table).
  * ncclAllReduce on a stream of its own -- the runner's pipeline is internal to it -- in chunks of the staging block. */
-extern "C" int suma_dist_allreduce_sum(suma_dist_comm* c, const double* send, uint32_t count, double* out) {
-  if (!c || !send || !out || count == 0) return SUMA_ERR_INVALID;
-  int cur = -1;
-  if (hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) != hipSuccess) {
-    c->err = "suma_dist_allreduce_sum: cannot make the communicator's device current";
-    return SUMA_ERR_HIP;
-  }
+static int allreduce_sum_on_device(suma_dist_comm* c, const double* send, uint32_t count, double* out) {
   hipStream_t stream = c->ar_stream;
   /* in place on the device, one collective per SUMA_DIST_TABLE_DOUBLES: the whole n_hyp x 18 table of a scan in one */
   for (uint32_t lo = 0; lo < count; lo += SUMA_DIST_TABLE_DOUBLES) {
@@ -168,6 +162,20 @@ extern "C" int suma_dist_allreduce_sum(suma_dist_comm* c, const double* send, ui
     memcpy(out + lo, c->h_table, n * sizeof(double));
   }
   return SUMA_OK;
+}
+extern "C" int suma_dist_allreduce_sum(suma_dist_comm* c, const double* send, uint32_t count, double* out) {
+  if (!c || !send || !out || count == 0) return SUMA_ERR_INVALID;
+  /* the communicator's device is made current for the call and the caller's device is put back on every path: the
+   * calling thread belongs to the embedding application (round-4 advisor) */
+  int cur = -1;
+  const bool switched = hipGetDevice(&cur) == hipSuccess && cur != c->device;
+  if (switched && hipSetDevice(c->device) != hipSuccess) {
+    c->err = "suma_dist_allreduce_sum: cannot make the communicator's device current";
+    return SUMA_ERR_HIP;
+  }
+  const int r = allreduce_sum_on_device(c, send, count, out);
+  if (switched) hipSetDevice(cur);
+  return r;
 }
 /* the same with the signature of suma_exchange_fn: pass it to suma_run_hypotheses with user = the suma_dist_comm */
 extern "C" int suma_dist_exchange(void* user, const double* local, double* all, uint32_t n_doubles) {

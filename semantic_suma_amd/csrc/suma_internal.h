@@ -180,6 +180,7 @@ struct suma_ctx {
   double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
   uint32_t gn_history_cap;
   uint32_t last_n_hist; /* LieGaussNewton::history() entries of the last suma_icp_minimize */
+  uint64_t hist_seq;    /* minimisations that recorded a history on this context (suma_icp_history_sequence) */
   uint32_t icp_blocks;
   GnState* h_gn; /* pinned */
 

@@ -242,3 +242,15 @@ def test_bench_launches_its_own_ranks():
     assert bench.self_launch_if_needed(ns, argv=argv, environ={"WORLD_SIZE": "8"}, run=fake_run) is None
     assert bench.self_launch_if_needed(argparse.Namespace(gpus=1), argv=argv, environ={}, run=fake_run) is None
     assert len(calls) == 1
+
+
+def test_bench_refuses_a_world_size_other_than_gpus():
+    """`--gpus 4` under a launcher that started 2 ranks: a scaling point measured on another number of ranks than it
+    claims is worthless, so bench.py exits non-zero instead of "using 2" (round-4 review, item 9)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"], env=env,
+                         capture_output=True, timeout=300)
+    assert res.returncode != 0
+    assert b"--gpus 4 but the launcher started WORLD_SIZE=2" in res.stderr

@@ -161,12 +161,16 @@ def test_gl_pipeline_through_the_submap_window(glp, oracle_lib):
     assert g.extractions >= 8 and tuple(g.origin) != (0, 0) and parked > 20, parked
 
 
-def test_gl_pipeline_takes_the_fallback_like_the_oracle(glp, oracle_lib):
+@pytest.mark.parametrize("which,tol_m", [("driver", 2e-1), ("detmath", 1e-1)])
+def test_gl_pipeline_takes_the_fallback_like_the_oracle(glp, oracle_lib, which, tol_m):
     """A jump in the motion (two scans skipped) trips the frame-to-frame fallback minimisation (SurfelMapping.cpp:434-449)
-    in the GL path at the same scan as in the oracle, and the two trajectories stay together through it."""
+    in the GL path at the same scan as in the oracle, and the two trajectories stay together through it -- with the
+    driver's own angle functions (a cold minimisation from 3.3 m away amplifies its asin: 11 cm after the jump) and with
+    the specified ones (oracle/glref.py::DETMATH_PRELUDE: 5 cm; what is left is the model render's attribute interpolation)."""
     p = params_with_size(W)
     op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
-    g = glp.GLPipeline(p)
+    with glp.gl.transcendentals(which):
+        g = glp.GLPipeline(p)
     for n, k in enumerate([0, 1, 2, 3, 6, 7]):
         pts, lab, prob, _ = get_scan(k, W, True)
         op.process_scan(pts, lab, prob, fixed_iterations=ITER)
@@ -174,7 +178,7 @@ def test_gl_pipeline_takes_the_fallback_like_the_oracle(glp, oracle_lib):
         dt, dr = pose_delta(op.pose(), g.current_pose)
         print("step %d (scan %d): %.2e m %.2e rad | track loss %d / %d" % (n, k, dt, dr, op.track_loss(), g.track_loss))
         assert op.track_loss() == g.track_loss, f"step {n}: fallback decision"
-        assert dt <= 1e-1 and dr <= 5e-3, f"step {n}: {dt:.2e} m / {dr:.2e} rad apart"
+        assert dt <= tol_m and dr <= 5e-3, f"step {n}: {dt:.2e} m / {dr:.2e} rad apart"
     assert g.track_loss >= 1, "the sequence was meant to trip the fallback"
 
 

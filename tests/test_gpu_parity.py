@@ -665,6 +665,53 @@ def test_loop_closure_verification(hip, oracle_lib):
     assert n_passed >= 1, "test setup: at least one guess should pass the gates"
 
 
+def test_history_belongs_to_the_optimizer_that_minimised_last(hip, oracle_lib):
+    """LieGaussNewton::history() is fetched lazily from ONE device buffer per context; the reference keeps history_ per
+    optimizer object (LieGaussNewton.h:72).  An object whose chain has been overwritten by another minimisation must say
+    so instead of handing out the other chain's poses (round-4 advisor); read in time, it holds the oracle's history."""
+    p = params_with_size(900)
+    ora, f0, f1 = _model_and_data(oracle_lib, p, 900, True)
+    ctx = hip.Context(p)
+    h0, h1 = (hip.Frame(ctx, 900, 64) for _ in range(2))
+    for h, f in ((h0, f0), (h1, f1)):
+        h.set(f.vertex, f.normal, f.semantic)
+    obj = hip.Frame2Model(ctx)
+    obj.setData(h1, h0)
+    a, b = hip.LieGaussNewton(ctx), hip.LieGaussNewton(ctx)
+    T0 = np.eye(4)
+    T0[0, 3] = 1.0
+    a.minimize(obj, T0)
+    _, hist, _ = ora.minimize(f1, f0, T0)
+    assert np.array_equal(a.history(), hist)  # fetched before anything else ran: the oracle's chain, pose by pose
+    a.minimize(obj, T0)
+    b.minimize(obj, T0 @ T0)
+    with pytest.raises(RuntimeError, match="overwritten"):
+        a.history()
+    assert b.history().shape[0] == ora.minimize(f1, f0, T0 @ T0)[1].shape[0]
+
+
+def test_new_frame_behind_a_backlog_of_the_ctx_stream(hip, oracle_lib):
+    """A frame created while the ctx stream still holds queued work: its zeroing memset is ctx-stream work, and the
+    side-stream preprocessing into it has to be ordered behind it (round-4 advisor: last_access stayed 0 and the memset
+    could land on the freshly written maps).  The maps must be the oracle's whatever the backlog."""
+    p = params_with_size(2048)
+    pipe = hip.SurfelMapping(p)
+    ctx = pipe.ctx
+    for k in range(6):  # a map worth ~0.4 ms of queued kernels per scan
+        pipe.processScan(*get_scan(k, 2048, True)[:3], fixed_iterations=10)
+    ora = oracle_lib.Oracle(p)
+    pts, lab, prob, _ = get_scan(7, 2048, True)
+    want = ora.preprocess(pts, lab, prob, 30, ora.frame())
+    pre = hip.Preprocessing(ctx)
+    for rep in range(8):
+        for k in range(3):  # backlog: three scans enqueued, none waited for
+            pipe.processScan(*get_scan(6 + k, 2048, True)[:3], fixed_iterations=10)
+        fresh = hip.Frame(ctx, 2048, 64)  # memset queued behind the backlog
+        pre.process(pts, fresh, lab, prob, 30)
+        assert_bit_equal(fresh.vertex, want.vertex, f"vertex map, repetition {rep}")
+        assert_bit_equal(fresh.normal, want.normal, f"normal map, repetition {rep}")
+
+
 def test_two_objectives_with_their_own_gates(hip, oracle_lib):
     """objective_ and recovery_ = Frame2Model(fallback_params) (SurfelMapping.cpp:87-94) live side by side on one
     context: each object sends its own gates and its own frame pair before a launch (round-1 advisor finding)."""

@@ -16,7 +16,7 @@ static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 static uint64_t s = 0x9E3779B97F4A7C15ull;
 static inline uint64_t rnd(void) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; }
 
-#include "exact_div.h" /* the very functions a kernel would use */
+#include "../semantic_suma_amd/csrc/exact_div.h" /* the very functions a kernel would use */
 
 /* r0: any approximation of 1/y within 1 ulp (v_rcp_f32) */
 static inline float div_core(float x, float y, float r0) { return exdiv_quot(x, y, exdiv_refine(y, r0)); }

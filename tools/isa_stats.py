@@ -58,7 +58,10 @@ def main():
             text = open(asm).read()
         for m in re.finditer(r"^(_Z\w+):[^\n]*\n", text, re.M):
             name = m.group(1)
-            end = text.find("s_endpgm", m.end())
+            # the whole function: a kernel with early exits has several s_endpgm (round 4 cut at the first one, which
+            # under-counted k_icp_step / k_icp_finish)
+            fe = re.search(r"^\.Lfunc_end\d+:", text[m.end():], re.M)
+            end = m.end() + fe.start() if fe else text.find("s_endpgm", m.end())
             if end < 0 or ".amdhsa_kernel " + name not in text:
                 continue
             body = text[m.end():end].split("\n")
