@@ -278,7 +278,7 @@ def test_gauss_newton_convergence_and_batch(hip, oracle_lib):
     assert np.array_equal(gn.pose(), Ts[0])
     # loose thresholds: the stopping tests of LieGaussNewton.cpp:64-66 must fire at the same iteration,
     # and the converged step is still applied (quirk B-4)
-    p2 = params_with_size(900, stopping_threshold=0.5, delta=2e-3)
+    p2 = params_with_size(900, stopping_threshold=0.5, delta=5e-3)  # (2e-3 under the round-4 arithmetic: the steps of this pair settle around 3 mm)
     ctx.set_params(p2)
     ora.set_params(p2)
     gn.minimize(obj, T0s[0])
