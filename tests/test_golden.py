@@ -63,3 +63,39 @@ def test_hip_reproduces_golden():
     obj.initialize(G["k6_T"])
     obj.jacobianProducts()
     assert np.array_equal(obj.acc, G["k6_acc"])
+
+
+def test_recorded_full_sequence_trace_belongs_to_this_oracle(oracle_lib):
+    """tests/golden/long_trace_4541.npz is what the GPU suite checks the literal BASELINE configs[1] run against
+    (tests/test_gpu_long.py, tools/long_parity.py --check).  It must have been recorded on THESE oracle sources -- the hash
+    in the file is compared, and the first 50 scans are replayed here (pose bits, statistics, counters, and the surfel
+    buffer's SHA-256 where the trace holds one): a stale trace fails on the build machine, not on the GPU box."""
+    import hashlib
+    import importlib.util
+    import os
+    from semantic_suma_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "long_trace_4541.npz")
+    if not os.path.exists(path):
+        pytest.skip("trace not recorded")
+    spec = importlib.util.spec_from_file_location("long_parity", os.path.join(root, "tools", "long_parity.py"))
+    lp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lp)
+    z = np.load(path)
+    assert str(z["oracle_source_sha"]) == lp.oracle_source_sha(), "re-record: python tools/long_parity.py --record tests/golden/long_trace_4541.npz"
+    assert int(z["scans"]) == 4541 and z["poses"].shape == (4541, 4, 4) and len(z["sha_idx"]) >= 90
+    W, H = int(z["width"]), int(z["height"])
+    p = params_with_size(W, H, max_surfels=int(z["max_surfels"]))
+    op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
+    keys = [str(k) for k in z["stat_keys"]]
+    sha_at = {int(k): i for i, k in enumerate(z["sha_idx"])}
+    every = int(z["every"])
+    for k in range(every):  # up to and including the first surfel-buffer checkpoint
+        pts, lab, prob = synth.generate_scan(k, n_azimuth=W, height=H)[:3]
+        op.process_scan(pts, lab, prob, fixed_iterations=10)
+        assert np.array_equal(op.pose(), z["poses"][k]), f"scan {k}: pose bits"
+        st = op.last_stats().as_dict()
+        assert [float(st[q]) for q in keys] == list(z["stats"][k]), f"scan {k}: statistics"
+        assert (*op.ctx.map_counts(), op.ctx.map_cached_surfels(), *op.ctx.map_submap_origin()) == tuple(int(v) for v in z["counts"][k])
+        if k in sha_at:
+            assert hashlib.sha256(op.ctx.map_surfels().tobytes()).digest() == z["sha"][sha_at[k]].tobytes()

@@ -12,6 +12,7 @@ export SUMA_SCAN_CACHE=/tmp/suma_scans
 B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0"
 timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
 timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
+timeout 300 python bench.py --steps 20 2>"$O/bench_driver_shape.err" | tail -1 > "$O/bench_driver_shape_steps20.json"
 timeout 900 $B --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
 timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
 bash tools/pmc_refresh.sh "$TAG" > "$O/pmc_refresh.log" 2>&1
@@ -22,10 +23,12 @@ SUMA_SEQ_CONCURRENT=2 timeout 400 python bench.py --mode sequences11 2>/dev/null
 timeout 300 python bench.py --mode adapter --adapter-scans 300 2>/dev/null | tail -1 > "$O/adapter_path_300_scans.json"
 timeout 300 python tools/ingest_bench.py 2>/dev/null | tail -1 > "$O/ingest.json"
 timeout 300 python tools/multi_seq.py 4 60 2>/dev/null | tail -1 > "$O/multi_seq.txt"
-# round 4: N = 2 ranks started by bench.py itself (gloo, both on this box's one GPU), the per-block phase timeline, the
-# Gauss-Newton station timeline, the HIP <-> GL interop probe
+# N = 2 ranks started by bench.py itself (gloo, both on this box's one GPU), the per-block phase timeline, the
+# Gauss-Newton station timeline
 SUMA_BENCH_FORCE_DEVICE=0 timeout 300 python bench.py --gpus 2 --backend gloo --steps 20 --cpu-scans 0 --adapter-scans 0 --no-kernel-events 2>/dev/null | tail -1 > "$O/bench_gpus2_self_launched_gloo.json"
 timeout 300 python tools/phase_timeline.py 250 30 2>&1 | tail -19 > "$O/phase_timeline.txt"
 timeout 300 python tools/gn_timeline.py 2>&1 | tail -14 > "$O/gn_timeline.txt"
-(g++ -std=c++11 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tools/gl_interop_probe.cpp -o /tmp/gl_probe -Lsemantic_suma_amd -lsuma_hip -L/opt/rocm/lib -lamdhip64 -ldl -Wl,-rpath,$PWD/semantic_suma_amd -Wl,-rpath,/opt/rocm/lib && /tmp/gl_probe) > "$O/gl_interop_probe.txt" 2>&1
+# LAST, so that it can never trail the sources again (round-4 review): BASELINE configs[1] verbatim, all 4541 scans of the
+# shipped build against the oracle's recorded trace -- the JSON names the kernel sources (kernel_source_sha) it ran on
+timeout 900 python tools/long_parity.py --check tests/golden/long_trace_4541.npz --out "$O/long_parity_4541_scans.json" 2>"$O/long_parity.err" | tail -1 | cut -c1-300
 cat "$O/pytest_gpu.txt"; cut -c1-400 "$O/bench.json"; cut -c1-300 "$O/bench_full_sequence_4541.json"; ls "$O"
