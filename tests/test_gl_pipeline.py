@@ -196,3 +196,34 @@ def test_oracle_agrees_with_the_committed_gl_trajectories(oracle_lib, fixture, t
         assert dt <= tol_m and dr <= tol_rad, f"scan {k}: {dt:.2e} m / {dr:.2e} rad from the GL path"
         gl_map = int(z["counts"][k][0])
         assert abs(op.ctx.map_size() - gl_map) <= 0.003 * gl_map + 5
+
+
+def test_oracle_agrees_with_the_committed_gl_gn_steps(oracle_lib):
+    """CPU twin of tests/test_gpu_gl_golden.py::test_acceptance_line_hip_against_the_reference_gl_path_per_iteration: the
+    committed GL-made Gauss-Newton steps (tests/golden/gl_gn_steps_900x64.npz; no Mesa needed here) against the oracle's
+    teacher-forced minimisations -- same poses before every iteration bit for bit, the pose after within 1e-4 m /
+    1e-5 rad of the reference's shaders in OpenGL."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "gl_gn_steps_900x64.npz"))
+    Wf, n, iters = int(z["W"]), int(z["scans"]), int(z["iterations"])
+    p = params_with_size(Wf)
+    op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
+    row = 0
+    for k in range(n):
+        pts, lab, prob, _ = get_scan(k, Wf, True)
+        if k >= 1:
+            ora = op.ctx
+            cur = ora.preprocess(pts, lab, prob, k, ora.frame())
+            pose32 = op.pose().astype(np.float32)
+            out = ora.frame(model=True)
+            ct = float(np.float32((1.0 - k / 10.0) * math.log(0.1 / 0.9) + np.float32(k / 10.0) * np.float32(p.confidence_threshold)))
+            ora.map_render(pose32, pose32, ct, out)
+            ora.set_params(params_with_size(Wf, max_iterations=iters, stopping_threshold=0.0, delta=0.0))
+            _, hist, _ = ora.minimize(cur, ora.map_frame(1), op.last_increment(), history_cap=iters + 1)
+            ora.set_params(p)
+            for it in range(iters):
+                assert np.array_equal(hist[it], z["pose_before"][row])
+                dt, dr = pose_delta(z["pose_after_gl"][row], hist[it + 1])
+                assert dt <= 1e-4 and dr <= 1e-5, f"scan {k} iteration {it}: {dt:.2e} m / {dr:.2e} rad"
+                row += 1
+        op.process_scan(pts, lab, prob, fixed_iterations=iters)
+    assert row == 40
