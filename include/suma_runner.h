@@ -43,6 +43,15 @@ typedef struct suma_sequence_result {
   char error[160];
 } suma_sequence_result;
 
+/* The reference's caller IS a native loop -- the visualizer thread calls SurfelMapping::processScan scan after scan
+ * (VisualizerWindow.cpp:556-600 -> SurfelMapping.cpp:175).  This is that loop on an EXISTING pipeline: the next
+ * job->n_scans scans of its sequence, without a reset and without a stream synchronisation at the end (the pipeline
+ * stays as asynchronous as after a single suma_pipeline_process_scan* call).  Host arrays take the blocking host-vector
+ * entry (no look-ahead), device arrays the resident entry.  *scans_done = scans that went through. */
+int suma_pipeline_run_scans(suma_pipeline* pipeline, const suma_sequence_job* job, int32_t fixed_iterations,
+                            uint32_t* scans_done, double* seconds_per_call /* NULL, or n_scans host times: a stall of the
+                            calling thread or of a copy helper shows up as ONE long call */);
+
 /* BASELINE configs[3]: runs the jobs in the order given (sort them longest first for an LPT schedule), at most
  * max_concurrent at a time, each through a pipeline of its own on hip_device.  Returns SUMA_OK when every job
  * succeeded; results[k] belongs to jobs[k] either way. */

@@ -185,6 +185,7 @@ def lib():
                                      C.POINTER(SequenceResult)]
     L.suma_run_hypotheses.argtypes = [C.POINTER(SumaParams), C.c_int, C.POINTER(HypothesisJob), i32, EXCHANGE_FN, vp, vp,
                                       vp, C.c_char_p]
+    L.suma_pipeline_run_scans.argtypes = [vp, C.POINTER(SequenceJob), i32, C.POINTER(u32), vp]
     L.suma_pipeline_last_increment.argtypes = [vp, vp]
     L.suma_pipeline_last_stats.argtypes = [vp, C.POINTER(IcpStats)]
     L.suma_pipeline_timestamp.restype = u32
@@ -815,6 +816,24 @@ class SurfelMapping:
         self.ctx.check(self.L.suma_pipeline_process_scan(self.h, _ptr(points), _ptr(labels), _ptr(probs),
                                                          points.shape[0], fixed_iterations),
                        "suma_pipeline_process_scan")
+
+    def runScans(self, scans, on_device: bool, fixed_iterations: int = 0, call_seconds=None) -> int:
+        """the caller's loop over processScan in native code (suma_pipeline_run_scans, include/suma_runner.h): the next
+        scans of this pipeline's sequence, one C call for all of them -- what the reference's visualizer thread does
+        (VisualizerWindow.cpp:556-600).  scans: device tuples (d_points, d_labels, d_probs, n) or host triples.
+        A prepared job (prepareScans) can be passed instead, so that no marshalling sits inside a timed region."""
+        job = scans if isinstance(scans, tuple) and len(scans) == 3 and isinstance(scans[0], SequenceJob) else self.prepareScans(scans, on_device)
+        done = C.c_uint32(0)
+        if call_seconds is not None:  # float64 array of at least n_scans entries: host time of every call
+            assert call_seconds.dtype == np.float64 and call_seconds.size >= job[0].n_scans
+        self.ctx.check(self.L.suma_pipeline_run_scans(self.h, C.byref(job[0]), fixed_iterations, C.byref(done),
+                                                      None if call_seconds is None else call_seconds.ctypes.data),
+                       "suma_pipeline_run_scans")
+        return done.value
+
+    def prepareScans(self, scans, on_device: bool):
+        refs, keep = _scan_refs(scans, on_device)
+        return SequenceJob(refs, len(scans), 1 if on_device else 0), refs, keep
 
     def processScanDevice(self, d_points: int, d_labels: int, d_probs: int, n: int, fixed_iterations: int = 0):
         """scan already resident in HBM (device addresses from Context.device_array)"""

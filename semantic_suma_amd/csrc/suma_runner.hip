@@ -59,6 +59,26 @@ static void run_one_sequence(suma_pipeline* s, const suma_sequence_job& job, int
   if (suma_map_size(suma_pipeline_ctx(s), &n) == SUMA_OK) res->map_surfels = n;
 }
 
+extern "C" int suma_pipeline_run_scans(suma_pipeline* s, const suma_sequence_job* job, int32_t fixed_iterations,
+                                       uint32_t* scans_done, double* seconds_per_call) {
+  if (!s || !job || (!job->scans && job->n_scans)) return SUMA_ERR_INVALID;
+  int r = SUMA_OK;
+  uint32_t k = 0;
+  double t_prev = seconds_per_call ? now_s() : 0.0;
+  for (; k < job->n_scans && r == SUMA_OK; ++k) {
+    const suma_scan_ref& sc = job->scans[k];
+    r = job->on_device ? suma_pipeline_process_scan_device(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations)
+                       : suma_pipeline_process_scan(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations);
+    if (seconds_per_call) {
+      const double t = now_s();
+      seconds_per_call[k] = t - t_prev;
+      t_prev = t;
+    }
+  }
+  if (scans_done) *scans_done = (r == SUMA_OK) ? k : (k ? k - 1 : 0);
+  return r;
+}
+
 extern "C" int suma_run_sequences(const suma_params* params, int hip_device, const suma_sequence_job* jobs,
                                   uint32_t n_jobs, uint32_t max_concurrent, int32_t fixed_iterations,
                                   suma_sequence_result* results) {

@@ -857,6 +857,29 @@ def test_async_ingest_equals_resident_scans(hip):
         a.prefetchScan(*scans_[3])  # all three slots staged
 
 
+def test_native_scan_loop_equals_scan_by_scan_calls(hip):
+    """suma_pipeline_run_scans (include/suma_runner.h): the caller's loop over processScan in native code, on an existing
+    pipeline, for resident and for host scans -- the same poses and the same map bytes as one call per scan, the count
+    of scans done, per-call host times filled in."""
+    width, n = 900, 8
+    p = params_with_size(width)
+    scans_ = [get_scan(k, width, True)[:3] for k in range(n)]
+    ref = hip.SurfelMapping(p)
+    for sc in scans_:
+        ref.processScan(*sc, fixed_iterations=10)
+    a, b = hip.SurfelMapping(p), hip.SurfelMapping(p)
+    dev = [tuple(a.ctx.device_array(x) for x in sc) + (sc[0].shape[0],) for sc in scans_]
+    a.processScanDevice(*dev[0], fixed_iterations=10)  # the loop continues a sequence that has already begun
+    assert a.runScans(dev[1:], True, fixed_iterations=10) == n - 1
+    secs = np.zeros(n, dtype=np.float64)
+    assert b.runScans(scans_, False, fixed_iterations=10, call_seconds=secs) == n
+    assert np.all(secs > 0.0) and secs.sum() < 5.0
+    for q in (a, b):
+        assert np.array_equal(q.getCurrentPose(), ref.getCurrentPose())
+        assert q.map.getAllSurfels().tobytes() == ref.map.getAllSurfels().tobytes()
+    assert a.runScans([], True) == 0
+
+
 _GATHER_SCRIPT = r"""
 import ctypes as C, os, sys
 import numpy as np
