@@ -44,7 +44,7 @@ typedef struct suma_sequence_result {
 } suma_sequence_result;
 
 /* The reference's caller IS a native loop -- the visualizer thread calls SurfelMapping::processScan scan after scan
- * (VisualizerWindow.cpp:556-600 -> SurfelMapping.cpp:175).  This is that loop on an EXISTING pipeline: the next
+ * (VisualizerWindow.cpp:636-689 -> SurfelMapping.cpp:175).  This is that loop on an EXISTING pipeline: the next
  * job->n_scans scans of its sequence, without a reset and without a stream synchronisation at the end (the pipeline
  * stays as asynchronous as after a single suma_pipeline_process_scan* call).  Host arrays take the blocking host-vector
  * entry (no look-ahead), device arrays the resident entry.  *scans_done = scans that went through. */

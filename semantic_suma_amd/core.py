@@ -820,7 +820,7 @@ class SurfelMapping:
     def runScans(self, scans, on_device: bool, fixed_iterations: int = 0, call_seconds=None) -> int:
         """the caller's loop over processScan in native code (suma_pipeline_run_scans, include/suma_runner.h): the next
         scans of this pipeline's sequence, one C call for all of them -- what the reference's visualizer thread does
-        (VisualizerWindow.cpp:556-600).  scans: device tuples (d_points, d_labels, d_probs, n) or host triples.
+        (VisualizerWindow.cpp:636-689).  scans: device tuples (d_points, d_labels, d_probs, n) or host triples.
         A prepared job (prepareScans) can be passed instead, so that no marshalling sits inside a timed region."""
         job = scans if isinstance(scans, tuple) and len(scans) == 3 and isinstance(scans[0], SequenceJob) else self.prepareScans(scans, on_device)
         done = C.c_uint32(0)
