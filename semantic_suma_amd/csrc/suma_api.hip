@@ -7,9 +7,20 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <set>
 
 #include "suma_internal.h"
+
+/* contexts that are alive: a frame may outlive its context (callers destroy in any order), so suma_frame_destroy asks
+ * here before it touches the context's frame-pointer caches */
+static std::mutex g_ctx_mu;
+static std::set<const suma_ctx*> g_live_ctx;
+static bool ctx_alive(const suma_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_ctx_mu);
+  return g_live_ctx.count(c) != 0;
+}
 
 static thread_local std::string g_create_error;
 
@@ -389,12 +400,20 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     suma_ctx_destroy(c);
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_live_ctx.insert(c);
+  }
   *out = c;
   return SUMA_OK;
 }
 
 extern "C" void suma_ctx_destroy(suma_ctx* c) {
   if (!c) return;
+  {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    g_live_ctx.erase(c);
+  }
   hipSetDevice(c->device);
   ingest_destroy(c);
   if (c->stream) hipStreamSynchronize(c->stream);
@@ -465,7 +484,7 @@ extern "C" void suma_frame_destroy(suma_frame* f) {
   if (!f) return;
   /* nothing the context remembers by frame POINTER may outlive the frame (a new frame can get the same address and,
    * at timestamp 0, the same version: round-4 advisor) */
-  if (suma_ctx* c = f->ctx) {
+  if (suma_ctx* c = ctx_alive(f->ctx) ? f->ctx : nullptr) {
     if (c->k8_fused_frame == f) c->k8_fused_frame = nullptr;
     if (c->gate_frame == f) c->gate_frame = nullptr;
     if (c->rendered.out == f) c->rendered.valid = false;
