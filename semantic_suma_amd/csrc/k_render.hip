@@ -171,6 +171,17 @@ extern "C" int suma_debug_k4_phases(unsigned long long* host, int reset) {
 }
 #endif
 
+/* Block barriers of k_render: everything the phases exchange lives in LDS (rank counters, candidate list, quad records,
+ * prefix), so with K4_PREFETCH they are LDS-only barriers -- a __syncthreads() also drains the vector-memory counter
+ * (s_waitcnt vmcnt(0)), i.e. it would wait for the next tile's loads at the first barrier behind their issue */
+#if !defined(K4_NO_PREFETCH)
+#define K4_PREFETCH 1 /* default since round 5; -DK4_NO_PREFETCH builds the round-4 form for A/B runs */
+#endif
+#ifdef K4_PREFETCH
+#define K4_BARRIER() lds_barrier()
+#else
+#define K4_BARRIER() __syncthreads()
+#endif
 #define RENDER_THREADS 256
 #define RENDER_WAVES (RENDER_THREADS / 64)
 #define RENDER_BATCH 2
@@ -181,7 +192,7 @@ __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const unsigned long long ball = __ballot(flag);
   if (lane == 0) s_w[wave] = __popcll(ball);
-  __syncthreads();
+  K4_BARRIER();
   uint32_t off = 0, tot = 0;
 #pragma unroll
   for (int w = 0; w < RENDER_WAVES; ++w) {
@@ -209,19 +220,39 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
   const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
   const int npass = a.merged ? 1 : 2;
   uint32_t trip = 0; /* counts rank barriers: the per-wave counters alternate between two sets (see the early-out) */
+  /* The three 16-byte loads of a lane's surfel are issued ONE TILE AHEAD (K4_PREFETCH): a block walks its tiles one after
+   * the other and used to start every trip with a cold round trip to HBM (2.3 of 15.5 us per trip, tools/phase_timeline.py).
+   * The record's registers are dead once the last phase 1a of a trip has consumed them, so the next tile's loads are
+   * issued right there and fly under phases 1b / 2 of this tile: no extra VGPRs (96, five waves per SIMD as before).
+   * Bit-identical by construction.  Measured (profiles/r05_k4_prefetch_experiment.txt): 50 M surfels 2.32 -> 2.11 ms
+   * (0.172 -> 0.190 of the HBM roofline); at the steady 1 M map, where a block makes ~3 trips and other blocks fill
+   * the gap anyway, 44.4 -> 43.7 us (inside the noise of the scan rate). */
+  float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
+  /* unconditional loads from a clamped (always valid) address: a lane beyond the map, or a trip beyond the last tile,
+   * re-reads the last record and never uses it (`live` and the K7 splat test i < S) -- no exec-masked branch, no merge
+   * with zeros, so the destination registers ARE the loop-carried ones and nothing has to wait for them here */
+  auto fetch_tile = [&](uint32_t t) {
+    const uint32_t tt = t < ntile ? t : ntile - 1u;
+    uint32_t j = (ntile - 1u - tt) * RENDER_THREADS + threadIdx.x;
+    j = j < S ? j : S - 1u;
+    s0 = sf[4 * (size_t)j];
+    s1 = sf[4 * (size_t)j + 1];
+    s2 = sf[4 * (size_t)j + 2];
+  };
+#ifdef K4_PREFETCH
+  if (ntile) fetch_tile(blockIdx.x);
+  /* the pass of a trip after which the record is dead (kernel-uniform) */
+  const int last_pass = a.merged ? 0 : (a.slot[1].enabled ? 1 : 0);
+#endif
   PH_BEGIN;
   for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     PH(7); /* loop overhead / previous tile's tail */
     const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
     const uint32_t i = blk0 + threadIdx.x;
-    float4 s0 = f4(0, 0, 0, 0), s1 = s0, s2 = s0;
-    bool live = false;
-    if (i < S) {
-      s0 = sf[4 * (size_t)i];
-      s1 = sf[4 * (size_t)i + 1];
-      s2 = sf[4 * (size_t)i + 2];
-      live = !(a.use_stability && !(s1.w > a.conf_threshold));
-    }
+#ifndef K4_PREFETCH
+    fetch_tile(tile);
+#endif
+    const bool live = (i < S) && !(a.use_stability && !(s1.w > a.conf_threshold));
     const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
@@ -273,6 +304,9 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
           }
         }
       }
+#ifdef K4_PREFETCH
+      if (sl == last_pass) fetch_tile(tile + gridDim.x); /* radius / count / stamps of THIS tile were copied out above */
+#endif
       uint32_t ncand;
       const uint32_t crank = render_block_rank(cand, s_w[trip & 1u], &ncand);
       trip += 1;
@@ -298,7 +332,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         r[8] = __uint_as_float(i);
         s_mask[crank] = (uint8_t)selmask;
       }
-      __syncthreads();
+      K4_BARRIER();
       PH(2); /* candidate list written + barrier */
       /* ---- phase 1b: dense lanes ---- */
       uint32_t ntests = 0;
@@ -377,7 +411,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       /* inclusive prefix of the test counts over the block */
       uint32_t incl = wave_inclusive_scan(ntests);
       if (lane == 63) s_w2[wave] = incl;
-      __syncthreads();
+      K4_BARRIER();
       uint32_t woff = 0, total = 0;
 #pragma unroll
       for (int w = 0; w < RENDER_WAVES; ++w) {
@@ -386,7 +420,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
         total += c;
       }
       s_incl[threadIdx.x] = incl + woff;
-      __syncthreads();
+      K4_BARRIER();
       PH(4); /* prefix over the block, two barriers */
       /* ---- phase 2 ---- */
       /* RENDER_BATCH tests per lane and trip: the fragments' keys are computed first, then the (device-
@@ -394,6 +428,11 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
        * -- one memory round trip per 512 tests instead of two per 256 (a batch of 4 is 0.5 % slower: 96 VGPRs
        * and 8 bytes of scratch against 93 and none).  The two strip triangles of a quad
        * write the same pixel, so their keys are min-combined into a single depth-tested write. */
+      /* The K7 read sits at the head of phase 2, where the compiler waits for it on the spot (it keeps the 1-bit result
+       * of the comparison below instead of the 64-bit value).  Issuing it EARLIER -- behind phase 1a, so that it flies
+       * under 1b and the prefix -- was built and measured in round 5: the fused pass 70.4 -> 82.0 us, -4.7 % scans/s
+       * (profiles/r05_k4_prefetch_experiment.txt): a staler value lets more splats through to the atomic, and the
+       * atomics of a hot pixel serialise at its memory channel.  The read belongs as close to the write as it is. */
       unsigned long long k7_cur = 0;
       if (k7_key != SUMA_EMPTY_KEY)
         k7_cur = __hip_atomic_load(&a.k7_zbuf[k7_pix], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -461,7 +500,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
       }
       if (k7_key < k7_cur) atomicMin(&a.k7_zbuf[k7_pix], k7_key);
       PH(5); /* phase 2: pixel tests, z-buffer reads, atomics */
-      __syncthreads(); /* the LDS lists are reused by the next slot / iteration */
+      K4_BARRIER(); /* the LDS lists are reused by the next slot / iteration */
       PH(6); /* closing barrier */
     }
   }
