@@ -96,6 +96,21 @@ int main(int argc, char** argv) {
       }
       std::memcpy(increment_before, increment, sizeof(increment));
     }
+    /* ---- the history belongs to the optimizer object that minimised last on the context (LieGaussNewton.h:72 keeps it
+     *      per object; here one device buffer per context, guarded by suma_icp_history_sequence) ---- */
+    {
+      suma_hip::LieGaussNewton gn2(ctx);
+      gn.minimize(objective, increment);
+      gn2.minimize(objective, increment);
+      bool threw = false;
+      try {
+        gn.history();
+      } catch (const std::runtime_error&) {
+        threw = true;
+      }
+      if (!threw) return 13;
+      if (gn2.history().size() < 32) return 14;
+    }
     /* ---- SurfelMapping::Stats (SurfelMapping.cpp:183-207, 393-394): the keys the untouched GUI plots ---- */
     suma_hip::SurfelMapping sm(p, 0);
     auto nop = [](suma_hip::SurfelMapping&) {};
