@@ -335,17 +335,6 @@ int suma_profile_enable(suma_ctx* ctx, int on);
 int suma_profile_reset(suma_ctx* ctx);
 int suma_profile_get(suma_ctx* ctx, suma_kernel_time* out, uint32_t cap);
 
-/* ---- visibility lists (no counterpart in the reference: its render passes draw every surfel, SurfelMap.cpp:847-1165).
- *      suma_map_update leaves, next to the map, two index lists of the surfels its kernels could not rule out for the two
- *      render passes that follow it (the post-update render from the update's pose; the post-ICP render + index map from
- *      a pose near the predicted next one); those passes walk a list instead of the map when a device-side test finds
- *      their pose inside the list's margin -- identical results, the lists are supersets by construction.
- *      Environment: SUMA_NO_VIS_LISTS switches the lists off; SUMA_VIS_VERIFY makes the passes walk the whole map and
- *      count every surfel that passes their first phase although its list would have missed it.
- *      out = { entries of list 0, entries of list 1, violations counted by SUMA_VIS_VERIFY (must be 0),
- *              render launches whose pose lay inside its list's margin }; the last two count since the last reset. */
-int suma_debug_vis_stats(suma_ctx* ctx, uint32_t out[4]);
-
 #ifdef __cplusplus
 }
 #endif

@@ -200,7 +200,6 @@ def lib():
     L.suma_profile_enable.argtypes = [vp, C.c_int]
     L.suma_profile_reset.argtypes = [vp]
     L.suma_profile_get.argtypes = [vp, C.POINTER(KernelTime), u32]
-    L.suma_debug_vis_stats.argtypes = [vp, C.POINTER(u32)]
     _LIB = L
     return L
 
@@ -277,13 +276,6 @@ class Context:
             self.check(n, "suma_profile_get")
         return [dict(name=buf[i].name.decode(), launches=int(buf[i].launches), total_ms=float(buf[i].total_ms),
                      bytes=float(buf[i].bytes)) for i in range(min(n, 64))]
-
-    def vis_stats(self):
-        """visibility lists of the last update (suma_hip.h): sizes of the two lists, SUMA_VIS_VERIFY violations, render
-        launches that found their pose inside a list's margin"""
-        buf = (C.c_uint32 * 4)()
-        self.check(self.L.suma_debug_vis_stats(self.h, buf), "suma_debug_vis_stats")
-        return dict(list0=int(buf[0]), list1=int(buf[1]), violations=int(buf[2]), list_passes=int(buf[3]))
 
     def close(self):
         if getattr(self, "owned", False) and self.h:

@@ -61,24 +61,6 @@ struct RenderArgs {
   int k7_same_proj; /* data and model images share one projection: the centre is projected once */
   proj_t k7_q;
   unsigned long long* k7_zbuf;
-  /* max_depth - min_depth of q / k7_q, formed on the host (the same IEEE subtraction): as kernel arguments they are scalar
-   * operands; formed in the kernel they are loop invariants the compiler parks in two VGPRs of a kernel that has none
-   * to spare (96: five waves per SIMD) */
-  float q_span, k7_span;
-  /* LIST MODE (vis_mode 1): the pass walks vis_list -- the surfels that the last update (k9_update / k10_generate:
-   * visibility bits, k_vis_compact) could not rule out for phase 1a from any pose within its margin of vis_ref -- instead
-   * of the whole map; a surfel that is not on the list fails phase 1a, so it contributes no fragment and no K7 splat and
-   * the z-buffers come out identical.  Whether THIS pass's pose lies inside the margin is tested on the device (the
-   * post-ICP pass takes its pose from HBM): if not, the kernel walks the whole map as before.
-   * vis_mode 2 (SUMA_VIS_VERIFY): the whole map is walked and every phase-1a survivor is checked against its flag byte. */
-  int vis_mode;
-  const uint32_t* vis_list; /* entries of chunk c at [c * VIS_CHUNK, + vis_cnt[c]) */
-  const uint32_t* vis_cnt;
-  float vis_ref[16];
-  float vis_lim_dt, vis_lim_tr; /* |t(T^-1 ref)| + rounding bound < lim_dt and trace(R(T^-1 ref)) > lim_tr */
-  const uint8_t* vis_flags;     /* verify: the flag bytes */
-  uint32_t vis_need;            /* verify: bits a phase-1a survivor must carry */
-  uint32_t* vis_counters;       /* [0] violations found by verify, [1] passes whose pose test held */
 };
 
 struct rvtx {
@@ -143,18 +125,6 @@ __device__ __forceinline__ unsigned long long raster_key(rvtx A, rvtx B, rvtx C,
     if (!((tu * tu + tv * tv) > 1.0f) && (z >= 0.0f && z <= 1.0f)) key = render_key(depth24(z), id, tie);
   }
   return key;
-}
-
-/* project01() of dev_math.h with the depth span handed in (RenderArgs.q_span): the same operations, the same values */
-__device__ __forceinline__ v3 project01_span(const proj_t& q, float span, v3 p) {
-  float depth = len3(p);
-  float yaw = sdm_atan2(p.y, p.x);
-  float pitch = -sdm_asin(p.z / depth);
-  v3 r;
-  r.x = 0.5f * ((-yaw * SUMA_INV_PI_F) + 1.0f);
-  r.y = 1.0f - ((pitch * SUMA_RAD2DEG_F) + q.fov_up) / q.fov;
-  r.z = (depth - q.min_depth) / span;
-  return r;
 }
 
 /* (inv_pose * surfelPose) * v, render_surfels.vert:44-48 */
@@ -234,41 +204,20 @@ __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, 
   return off + __popcll(ball & ((1ull << lane) - 1ull));
 }
 
-struct RenderShared {
-  float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
-  int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
-  uint32_t s_incl[RENDER_THREADS];
-  uint32_t s_w[2][RENDER_WAVES], s_w2[RENDER_WAVES];
-  uint8_t s_mask[RENDER_THREADS]; /* slot mask of a candidate, by candidate rank */
-};
-
-/* The pass proper.  LIST = false: the whole map, 256 consecutive surfels per trip (the code of rounds 1-5, unchanged).
- * LIST = true: the visibility list of the last update (see RenderArgs): the list keeps the map's chunks of VIS_CHUNK
- * surfels apart -- chunk c's entries are list[c * VIS_CHUNK ..+ cnt[c]), ascending -- so that no launch has to know a
- * list's size and the newest surfels (the expensive ones: in view, with pixel tests) still come first; a trip takes
- * LIST_TILE entries of one chunk, a tile beyond its chunk's count is skipped.  VERIFY: see k_render. */
-#define VIS_CHUNK 2048u
-#ifndef LIST_TILE
-#define LIST_TILE 128u
-#endif
-#define LIST_TPC (VIS_CHUNK / LIST_TILE) /* tiles per chunk */
-static_assert(LIST_TILE <= RENDER_THREADS && VIS_CHUNK % LIST_TILE == 0, "list tiles");
-template <bool LIST, bool VERIFY>
-__device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& sh, const uint32_t S, const bool verify) {
-  auto& s_cand = sh.s_cand;
-  auto& s_rec = sh.s_rec;
-  auto& s_incl = sh.s_incl;
-  auto& s_w = sh.s_w;
-  auto& s_w2 = sh.s_w2;
-  auto& s_mask = sh.s_mask;
+__global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
+  __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
+  __shared__ int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
+  __shared__ uint32_t s_incl[RENDER_THREADS];
+  __shared__ uint32_t s_w[2][RENDER_WAVES], s_w2[RENDER_WAVES];
+  __shared__ uint8_t s_mask[RENDER_THREADS]; /* slot mask of a candidate, by candidate rank */
+  const uint32_t S = a.ds->n_surfels;
   const float4* __restrict__ sf = reinterpret_cast<const float4*>(a.surfels);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   /* Tiles are taken from the END of the surfel array first: the array is in creation order, so its tail holds
    * the surfels around the sensor's recent positions -- the ones in view, with pixel tests to run -- and its
    * head mostly surfels that leave after phase 1a.  Dispatching the expensive tiles first keeps the cheap
    * ones for the kernel's tail. */
-  const uint32_t nchunk = (S + VIS_CHUNK - 1u) / VIS_CHUNK;
-  const uint32_t ntile = LIST ? nchunk * LIST_TPC : (S + RENDER_THREADS - 1) / RENDER_THREADS;
+  const uint32_t ntile = (S + RENDER_THREADS - 1) / RENDER_THREADS;
   const int npass = a.merged ? 1 : 2;
   uint32_t trip = 0; /* counts rank barriers: the per-wave counters alternate between two sets (see the early-out) */
   /* The three 16-byte loads of a lane's surfel are issued ONE TILE AHEAD (K4_PREFETCH): a block walks its tiles one after
@@ -291,41 +240,19 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
     s2 = sf[4 * (size_t)j + 2];
   };
 #ifdef K4_PREFETCH
-  if (!LIST && ntile) fetch_tile(blockIdx.x);
+  if (ntile) fetch_tile(blockIdx.x);
   /* the pass of a trip after which the record is dead (kernel-uniform) */
   const int last_pass = a.merged ? 0 : (a.slot[1].enabled ? 1 : 0);
 #endif
   PH_BEGIN;
   for (uint32_t tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     PH(7); /* loop overhead / previous tile's tail */
-    uint32_t i;
-    bool in_range;
-    if (LIST) s0 = s1 = s2 = f4(0, 0, 0, 0); /* nothing of the record is carried from trip to trip (kills the loop-carried copies) */
-    if (LIST) {
-      /* The surfel id does not get a register of its own across phase 1a (the pass runs at exactly 96 VGPRs; one more live
-       * value spills): it is parked in this thread's word of s_incl, which nothing touches before the prefix behind phase
-       * 1b (the previous trip's readers of s_incl are behind that trip's closing barrier; a trip that ended at its
-       * early-out has not read it at all), and read back where it is used -- the K7 key and the candidate record. */
-      /* chunks from the end of the map, a chunk's tiles in ascending order; block-uniform skip before any barrier */
-      const uint32_t c = nchunk - 1u - tile / LIST_TPC, k0 = (tile % LIST_TPC) * LIST_TILE;
-      const uint32_t cnt = a.vis_cnt[c];
-      if (k0 >= cnt) continue;
-      const uint32_t off = k0 + threadIdx.x;
-      in_range = threadIdx.x < LIST_TILE && off < cnt;
-      i = a.vis_list[(size_t)c * VIS_CHUNK + (in_range ? off : k0)]; /* a lane without an entry re-reads the tile's first */
-      s_incl[threadIdx.x] = i;
-      s0 = sf[4 * (size_t)i];
-      s1 = sf[4 * (size_t)i + 1];
-      s2 = sf[4 * (size_t)i + 2];
-    } else {
-      const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
-      i = blk0 + threadIdx.x;
-      in_range = i < S;
+    const uint32_t blk0 = (ntile - 1u - tile) * RENDER_THREADS;
+    const uint32_t i = blk0 + threadIdx.x;
 #ifndef K4_PREFETCH
-      fetch_tile(tile);
+    fetch_tile(tile);
 #endif
-    }
-    const bool live = in_range && !(a.use_stability && !(s1.w > a.conf_threshold));
+    const bool live = (i < S) && !(a.use_stability && !(s1.w > a.conf_threshold));
     const float radius = s0.w, count = s2.w;
     const int32_t creation = (int32_t)count;
     const int32_t ts = (int32_t)__float_as_uint(s2.x);
@@ -348,7 +275,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
           selmask = ((slot.mode == 0) ? sel_old : sel_new) ? (1u << sl) : 0u;
       }
       const bool selected = selmask != 0;
-      const bool k7 = (sl == 0) && a.k7_enabled && in_range;
+      const bool k7 = (sl == 0) && a.k7_enabled && (i < S);
       bool cand = false;
       unsigned long long k7_key = SUMA_EMPTY_KEY;
       uint32_t k7_pix = 0;
@@ -359,15 +286,15 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
         float lp = len3(p);
         if (dot3(n, divs3(neg3(p), lp)) > 0.01f) { /* front facing (render_surfels.geom:83, gen_indexmap.vert:68) */
           v3 pp = mk3(0, 0, 0);
-          if (selected || a.k7_same_proj) pp = project01_span(a.q, a.q_span, p);
+          if (selected || a.k7_same_proj) pp = project01(a.q, p);
           if (k7) {
             /* K7 for every surfel (no stability / age gating): nearest visible surfel per data pixel */
-            const v3 pr = a.k7_same_proj ? pp : project01_span(a.k7_q, a.k7_span, p);
+            const v3 pr = a.k7_same_proj ? pp : project01(a.k7_q, p);
             float fx = sdm_floor(pr.x * a.k7_q.width), fy = sdm_floor(pr.y * a.k7_q.height);
             float zn = 2.0f * pr.z - 1.0f;
             if (fx >= 0.0f && fx < a.k7_q.width && fy >= 0.0f && fy < a.k7_q.height && zn >= -1.0f && zn <= 1.0f) {
               /* depth-tested write deferred to phase 2, where its memory round trip overlaps the raster's */
-              k7_key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | (LIST ? s_incl[threadIdx.x] : i);
+              k7_key = ((unsigned long long)depth24(0.5f * zn + 0.5f) << 32) | i;
               k7_pix = (uint32_t)(int32_t)fy * (uint32_t)a.k7_q.W + (uint32_t)(int32_t)fx;
             }
           }
@@ -377,12 +304,8 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
           }
         }
       }
-      if (VERIFY && verify && in_range && (cand || k7_key != SUMA_EMPTY_KEY)) {
-        /* SUMA_VIS_VERIFY: a phase-1a survivor whose flag byte would have kept it off the list */
-        if ((a.vis_flags[LIST ? s_incl[threadIdx.x] : i] & a.vis_need) != a.vis_need) atomicAdd(&a.vis_counters[0], 1u);
-      }
 #ifdef K4_PREFETCH
-      if (!LIST && sl == last_pass) fetch_tile(tile + gridDim.x); /* radius / count / stamps of THIS tile were copied out above */
+      if (sl == last_pass) fetch_tile(tile + gridDim.x); /* radius / count / stamps of THIS tile were copied out above */
 #endif
       uint32_t ncand;
       const uint32_t crank = render_block_rank(cand, s_w[trip & 1u], &ncand);
@@ -406,7 +329,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
         r[5] = n.z;
         r[6] = radius;
         r[7] = ppx;
-        r[8] = __uint_as_float(LIST ? s_incl[threadIdx.x] : i);
+        r[8] = __uint_as_float(i);
         s_mask[crank] = (uint8_t)selmask;
       }
       K4_BARRIER();
@@ -439,7 +362,7 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
           const float y01 = 1.0f - ((pitch * SUMA_RAD2DEG_F) + a.q.fov_up) / a.q.fov;
           /* window depth as shader (gl_Position.z = 2 z01 - 1, render_surfels.geom:104-117) and viewport (z_w = 0.5 z_ndc +
            * 0.5) form it: in fp32 that is z01 again for only 84 % of the values */
-          Z[k] = 0.5f * (2.0f * ((depth - a.q.min_depth) / a.q_span) - 1.0f) + 0.5f;
+          Z[k] = 0.5f * (2.0f * ((depth - a.q.min_depth) / (a.q.max_depth - a.q.min_depth)) - 1.0f) + 0.5f;
           const float yw = y01 * a.q.height;
           if (sdm_isnan(yw) || sdm_isnan(Z[k])) bad = true;
           Y[k] = (int32_t)sdm_floor(yw * 256.0f + 0.5f);
@@ -584,46 +507,6 @@ __device__ __forceinline__ void render_body(const RenderArgs& a, RenderShared& s
   PH_END(g_k4_phase);
 }
 
-/* VERIFY: the SUMA_VIS_VERIFY build of the pass (a kernel of its own, so that the product kernel carries none of it) */
-template <bool VERIFY>
-__global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
-  __shared__ RenderShared sh;
-  const uint32_t S = a.ds->n_surfels;
-  /* list mode: is this pass's pose inside the margin the list was made for?  D = T^-1 * ref (float; the bound `err`
-   * covers the cancellation of the two world-frame translations); a NaN fails both comparisons.  Decided HERE, once, and
-   * the two forms of the pass are two instantiations: neither carries the other's state through its loop (the kernel
-   * runs at exactly 96 VGPRs / 102 SGPRs; one more live value spills) */
-  bool pose_ok = false;
-  if (a.vis_mode != 0) {
-    float ib[16];
-    if (a.inv_pose_dev != nullptr) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) ib[k] = a.inv_pose_dev[k];
-    } else if (a.merged) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) ib[k] = a.slot[1].inv_pose.m[k];
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) ib[k] = a.slot[0].inv_pose.m[k];
-    }
-    const float* P = a.vis_ref;
-    float tr = 0.0f, d2 = 0.0f;
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const float t = ((ib[r] * P[12] + ib[4 + r] * P[13]) + ib[8 + r] * P[14]) + ib[12 + r];
-      d2 += t * t;
-      tr += (ib[r] * P[4 * r] + ib[4 + r] * P[4 * r + 1]) + ib[8 + r] * P[4 * r + 2];
-    }
-    const float err = 1e-6f * (((sdm_abs(P[12]) + sdm_abs(P[13])) + sdm_abs(P[14])) + ((sdm_abs(ib[12]) + sdm_abs(ib[13])) + sdm_abs(ib[14])));
-    pose_ok = (__builtin_sqrtf(d2) + err < a.vis_lim_dt) && (tr > a.vis_lim_tr);
-    if (pose_ok && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&a.vis_counters[1], 1u);
-  }
-  if (!VERIFY && pose_ok)
-    render_body<true, false>(a, sh, S, false);
-  else
-    render_body<false, VERIFY>(a, sh, S, pose_ok);
-}
-
 __device__ __forceinline__ uint32_t key_id(unsigned long long key, int tie) {
   uint32_t low = (uint32_t)(key & 0xffffffffull);
   return tie == TIE_LOW_INDEX ? low : (0xffffffffu - low);
@@ -724,13 +607,6 @@ static void set_m4(m4& d, const float* s) {
   for (int i = 0; i < 16; ++i) d.m[i] = s[i];
 }
 
-static uint32_t stream_grid(suma_ctx* c);
-static void run_render(suma_ctx* c, const RenderArgs& a, uint32_t grid) {
-  if (a.vis_mode == 2)
-    k_render<true><<<grid, RENDER_THREADS, 0, c->ls>>>(a);
-  else
-    k_render<false><<<grid, RENDER_THREADS, 0, c->ls>>>(a);
-}
 static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   RenderArgs a;
   a.surfels = c->surfels[c->cur];
@@ -749,49 +625,7 @@ static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   a.k7_q = c->pd;
   a.k7_same_proj = (memcmp(&c->pd, &c->pm, sizeof(proj_t)) == 0) ? 1 : 0;
   a.k7_zbuf = c->zbuf_data;
-  {
-    volatile float s0 = a.q.max_depth - a.q.min_depth, s1 = a.k7_q.max_depth - a.k7_q.min_depth; /* plain binary32 subtractions */
-    a.q_span = s0;
-    a.k7_span = s1;
-  }
-  a.vis_mode = 0;
-  a.vis_list = nullptr;
-  a.vis_cnt = nullptr;
-  for (int k = 0; k < 16; ++k) a.vis_ref[k] = 0.0f;
-  a.vis_lim_dt = a.vis_lim_tr = 0.0f;
-  a.vis_flags = nullptr;
-  a.vis_need = 0;
-  a.vis_counters = nullptr;
   return a;
-}
-/* list mode for this launch (which = 0: a render from the last update's pose, 1: from a pose near the predicted next
- * one), if the last update left lists for exactly this map and these parameters; returns the grid to launch */
-static uint32_t render_use_list(suma_ctx* c, RenderArgs& a, int which, float conf_threshold) {
-  const uint32_t full = stream_grid(c);
-  if (c->vis_off || !c->vis.valid || c->vis.map_version != c->map_version || c->vis.params_version != c->params_version ||
-      !a.k7_same_proj)
-    return full;
-  /* one pass per trip only (both slots from one pose, or one slot): render_body<LIST> parks the surfel id in LDS words
-   * that a second pass of the same trip would find overwritten */
-  if (!a.merged && a.slot[1].enabled) return full;
-  /* list 0 has the stability gate folded in: only for a pass that gates with the same threshold */
-  if (which == 0 && memcmp(&conf_threshold, &c->vis.conf_threshold, sizeof(float)) != 0) return full;
-  a.vis_mode = c->vis_verify ? 2 : 1;
-  a.vis_list = c->vis_list[which];
-  a.vis_cnt = c->vis_cnt[which];
-  memcpy(a.vis_ref, c->vis.ref[which], sizeof(a.vis_ref));
-  a.vis_lim_dt = c->vis.lim_dt[which];
-  a.vis_lim_tr = c->vis.lim_tr[which];
-  a.vis_flags = c->vis_flags;
-  a.vis_need = which == 0 ? 5u : 2u;
-  a.vis_counters = &c->ds->vis_violations;
-  /* one block per list tile of the map's chunks, whatever the chunks hold (a tile beyond its chunk's count returns at
-   * once); a pass that falls back to the whole map finds more blocks than tiles */
-  if (a.vis_mode != 1) return full;
-  uint64_t blocks = (((uint64_t)c->known_surfels + 2 * c->P + VIS_CHUNK - 1) / VIS_CHUNK) * LIST_TPC;
-  if (blocks > SUMA_RENDER_MAX_BLOCKS) blocks = SUMA_RENDER_MAX_BLOCKS;
-  if (blocks < 256) blocks = 256;
-  return (uint32_t)blocks;
 }
 static uint32_t stream_grid(suma_ctx* c) {
   /* sized from the last surfel count the host has seen; the kernels grid-stride over the
@@ -842,11 +676,9 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[1].inv_pose, inv_new);
     /* outside loop closures currentPose_old_ == currentPose_new_ (SurfelMapping.cpp:457-458): one trip per tile */
     a.merged = (memcmp(inv_old, inv_new, sizeof(inv_old)) == 0 && !getenv("SUMA_RENDER_NO_MERGE")) ? 1 : 0;
-    /* one pose for both slots: the post-update render of a scan -- the update's list of what can be in view from there */
-    const uint32_t grid = a.merged ? render_use_list(c, a, 0, conf_threshold) : stream_grid(c);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      run_render(c, a, grid);
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -874,7 +706,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[0].inv_pose, inv_old);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      run_render(c, a, stream_grid(c));
+      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -913,11 +745,9 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   a.slot[0].zbuf = c->zbuf_a;
   set_m4(a.slot[0].inv_pose, inv);
   a.k7_enabled = fuse_k7;
-  /* a render from one pose, normally the pose after this scan's ICP: the update's list for poses near its prediction */
-  const uint32_t grid = render_use_list(c, a, 1, conf_threshold);
   {
     ProfScope ps(c, fuse_k7 ? "k4k7_render_indexmap" : "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    run_render(c, a, grid);
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv);
@@ -962,7 +792,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
   set_m4(a.slot[1].inv_pose, inv_new);
   {
     ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    run_render(c, a, stream_grid(c));
+    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv_old);

@@ -276,20 +276,6 @@ struct UpdArgs {
   float* poses_inv_w;
   uint32_t pose_idx;
   int write_pose;
-  /* Visibility bits (see vis_may_pass): one byte per surviving surfel at its final index; NULL = off.
-   * [0]: margins of the bit for a render from THIS update's pose (the post-update render; they only absorb the rounding
-   * differences between this kernel's transform and k_render's), [1]: of the bit for a render from any pose within
-   * (dt, dth) of the predicted next pose = pose * X0, of which vis_t0 is the translation and vis_r2 the third column
-   * of the rotation.  vis_sin_lo / _hi: sines of the lowest / highest elevation that projects into the image,
-   * vis_min_depth / _max_depth: the range gate, both already widened by the host (suma_api.hip, vis_prepare). */
-  uint8_t* vis_flags;
-  float vis_dt[2], vis_dth[2];
-  float vis_t0[3], vis_r2[3];
-  float vis_sin_lo, vis_sin_hi, vis_min_depth, vis_max_depth;
-  float vis_conf_threshold;
-  /* bit 0 from what k9_prepare computes anyway (its own facing cosine, image row and range): the margins of [0] as
-   * constants for surfels at least 1 m away -- facing cosine, image row y01 (suma_api.hip, vis_prepare) */
-  float vis0_f, vis0_y;
 };
 
 __device__ __forceinline__ void load_pose(const float* __restrict__ table, int32_t idx, float* M) {
@@ -375,45 +361,11 @@ struct K9Pre {
   int32_t tx, ty;
   uint32_t rpix;
   bool in_tex, visible, inside;
-  uint32_t vis; /* bit 0 / 1: see vis_may_pass */
 };
 struct K9Rec {
   float4 dv, dn, dx;
   unsigned long long k7key;
 };
-
-/* Visibility bits: a CONSERVATIVE statement about phase 1a of k_render (render_surfels.geom:76-103 / gen_indexmap.vert:
- * 62-81: front facing, inside the range gate, inside the field of view) for a surfel this kernel has in its sensor frame
- * anyway.  Returns 0 only when the surfel PROVABLY fails those tests from every sensor pose T with
- *     |translation(T^-1 * P)| <= dt,   angle(rotation(T^-1 * P)) <= dth,     P = pose * X0  (t0, r2 describe X0):
- * with u = vertex - t0 (the surfel seen from P's origin, r = |u|), a pose inside the margin sees the surfel at a range
- * within r +- dt and, while dt < r, in a direction that differs from u's by at most alpha = asin(dt / r) <= (pi / 2) dt / r,
- * plus dth of rotation for everything that is measured against the sensor's axes.  The facing cosine is 1-Lipschitz in the
- * direction (rotation invariant), the sine of the elevation is 1-Lipschitz in the elevation: the two comparisons below.
- * k_render's normal is not normalised (ln2 = its squared length here); every comparison is written so that a NaN keeps the
- * surfel.  A bit that is set costs the render pass a surfel it would have rejected itself -- never a result. */
-/* x * ln < 0.009 for ln = sqrt(ln2) >= 0, without the root (false for NaN, as the comparison it stands for) */
-__device__ __forceinline__ bool vis_facing_fails(float x, float ln2) { return (x < 0.0f) || ((x * x) * ln2 < 8.1e-5f); }
-
-__device__ __forceinline__ uint32_t vis_may_pass(const UpdArgs& a, v3 vertex, v3 normal, float ln2, v3 t0, v3 r2, float dt,
-                                                 float dth) {
-  /* hardware rsq (1 ulp) instead of the specified square root and division: nothing here reaches a result, and the
-   * margins are five orders of magnitude above an ulp */
-  const v3 u = sub3(vertex, t0);
-  const float rr = dot3(u, u);
-  const float inv_r = __builtin_amdgcn_rsqf(rr);
-  const float r = rr * inv_r;
-  const float alpha = (1.5708f * dt) * inv_r;
-  const bool dir_bounded = alpha < 1.5708f; /* dt < r: only then does the margin bound the direction at all (false for NaN) */
-  const float f = -dot3(normal, u) * inv_r;
-  const float s = dot3(r2, u) * inv_r;
-  const float m = alpha + dth + 1e-3f;
-  bool rej = vis_facing_fails(f + alpha + 1e-3f, ln2); /* k_render: dot(n, -p / |p|) > 0.01, n of length ln */
-  rej = rej || (s < a.vis_sin_lo - m) || (s > a.vis_sin_hi + m);
-  rej = rej && dir_bounded;
-  rej = rej || (r < a.vis_min_depth - dt) || (r > a.vis_max_depth + dt); /* triangle inequality: holds for any dt */
-  return rej ? 0u : 1u;
-}
 
 __device__ __forceinline__ K9Pre k9_prepare(const UpdArgs& a, const Surfel4& in) {
   K9Pre p;
@@ -423,26 +375,9 @@ __device__ __forceinline__ K9Pre k9_prepare(const UpdArgs& a, const Surfel4& in)
   p.old_position = m4_point(Ps, xyz(in.a));
   p.old_normal = m4_dir(Ps, xyz(in.b));
   const v3 vertex = m4_point(a.inv_pose.m, p.old_position);
-  const v3 nraw = m4_dir(a.inv_pose.m, p.old_normal);
-  const v3 normal = normalize3(nraw);
-  const float lv = len3(vertex);
-  const float fd = dot3(normal, divs3(neg3(vertex), lv));
-  p.visible = fd > 0.0f;
+  const v3 normal = normalize3(m4_dir(a.inv_pose.m, p.old_normal));
+  p.visible = dot3(normal, divs3(neg3(vertex), len3(vertex))) > 0.0f;
   const v3 pr = project01(a.q, vertex);
-  p.vis = 3u;
-  if (a.vis_flags != nullptr) { /* launch-uniform */
-    /* (k9_update is not latency- but issue-sensitive here: its sixteen waves walk this phase in lock step, every
-     * instruction costs a tile 16 issue cycles per SIMD -- two full vis_may_pass calls made the kernel 5 us longer) */
-    const float ln2 = dot3(nraw, nraw);
-    /* bit 0, a render from THIS pose: this kernel's own facing cosine, image row and range, widened by the margin --
-     * which is a constant for a surfel at least 1 m away (direction: asin(dt / r) <= 1.5708 dt); nearer ones are kept */
-    bool rej0 = vis_facing_fails(fd + a.vis0_f, ln2) || (pr.y < -a.vis0_y) || (pr.y > 1.0f + a.vis0_y) ||
-                (lv < a.vis_min_depth - a.vis_dt[0]) || (lv > a.vis_max_depth + a.vis_dt[0]);
-    rej0 = rej0 && (lv > 1.0f);
-    p.vis = (rej0 ? 0u : 1u) | (vis_may_pass(a, vertex, normal, ln2, mk3(a.vis_t0[0], a.vis_t0[1], a.vis_t0[2]),
-                                             mk3(a.vis_r2[0], a.vis_r2[1], a.vis_r2[2]), a.vis_dt[1], a.vis_dth[1])
-                                << 1);
-  }
   const float imx = sdm_floor(pr.x * a.q.width) + 0.5f, imy = sdm_floor(pr.y * a.q.height) + 0.5f;
   p.imz = pr.z;
   /* texel fetch at the exact centre (imx, imy); border (0) outside or for NaN */
@@ -701,16 +636,14 @@ __global__ void __launch_bounds__(K9_THREADS)
         const uint32_t slot = s_slot[pb][c >> 2];
         const float4 v = s_out[pb][slot][c & 3u];
         store_stream(&dst4[d], v);
-        const uint32_t eb = s_ext[pb][slot]; /* bit 0: in the extracted tile; bits 1..3: visibility bits */
-        if (a.vis_flags != nullptr && (c & 3u) == 0) a.vis_flags[d >> 2] = (uint8_t)(eb >> 1);
         if (XF) {
-          if (eb & 1u) {
+          if (s_ext[pb][slot]) {
             const uint32_t xr = prefix_x + s_xrank[pb][slot];
             if (xr < SUMA_EXTRACT_CAPACITY && (uint64_t)xbase + xr < a.x_cap)
               store_stream(&xdst4[4ull * ((uint64_t)xbase + xr) + (c & 3u)], v);
           }
         } else if (a.ex_flags != nullptr && (c & 3u) == 0) {
-          a.ex_flags[d >> 2] = (uint8_t)(eb & 1u);
+          a.ex_flags[d >> 2] = s_ext[pb][slot];
         }
       }
     }
@@ -775,17 +708,7 @@ __global__ void __launch_bounds__(K9_THREADS)
         const uint32_t slot = (uint32_t)u * K9_THREADS + threadIdx.x;
         xt[u] = in_tile && emit[u];
         xb[u] = XF ? __ballot(xt[u]) : 0ull;
-        /* visibility bits of the surviving record: what k9_prepare found for the surfel as it was, unless the update
-         * moved it (position / normal: then the render passes look for themselves); bit 2: stable at the threshold the
-         * render passes gate with (k_render: !(use_stability && !(confidence > threshold))) */
-        uint32_t vb = 7u;
-        if (aB.vis_flags != nullptr) {
-          const bool moved = (o.a.x != in[u].a.x) || (o.a.y != in[u].a.y) || (o.a.z != in[u].a.z) || (o.b.x != in[u].b.x) ||
-                             (o.b.y != in[u].b.y) || (o.b.z != in[u].b.z);
-          vb = moved ? 3u : pre[u].vis;
-          if (!(aB.use_stability && !(o.b.w > aB.vis_conf_threshold))) vb |= 4u;
-        }
-        s_ext[buf][slot] = (uint8_t)((in_tile ? 1u : 0u) | (vb << 1));
+        s_ext[buf][slot] = in_tile ? 1 : 0;
         s_out[buf][slot][0] = o.a;
         s_out[buf][slot][1] = o.b;
         s_out[buf][slot][2] = o.c;
@@ -995,9 +918,6 @@ __global__ void __launch_bounds__(SUMA_TILE) k10_generate(UpdArgs a) {
       uint64_t dst = (uint64_t)base + s_prefix + (XF ? (rk & 0xffffu) : rk);
       if (dst < aT.max_surfels) {
         store_surfel(aT.out, (uint32_t)dst, s);
-        /* a new surfel is in view by construction; bit 2 as in k9_update */
-        if (aT.vis_flags != nullptr)
-          aT.vis_flags[dst] = (uint8_t)(3u | ((!(aT.use_stability && !(s.b.w > aT.vis_conf_threshold))) ? 4u : 0u));
         if (XF) {
           if (in_tile) {
             const uint64_t xr = (uint64_t)xfirst + s_prefix_x + (rk >> 16);
@@ -1116,26 +1036,6 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
   a.ex_cx = ex ? ex[0] : 0.0f;
   a.ex_cy = ex ? ex[1] : 0.0f;
   a.ex_extent = ex ? ex[2] : 0.0f;
-  /* visibility bits: suma_map_update has filled c->vis_params (margins, prediction) when the lists are in use */
-  a.vis_flags = c->vis_params.enabled ? c->vis_flags : nullptr;
-  if (a.vis_flags) {
-    const VisParams& vp = c->vis_params;
-    for (int k = 0; k < 2; ++k) {
-      a.vis_dt[k] = vp.dt[k];
-      a.vis_dth[k] = vp.dth[k];
-    }
-    for (int k = 0; k < 3; ++k) {
-      a.vis_t0[k] = vp.t0[k];
-      a.vis_r2[k] = vp.r2[k];
-    }
-    a.vis_sin_lo = vp.sin_lo;
-    a.vis_sin_hi = vp.sin_hi;
-    a.vis_min_depth = vp.min_depth;
-    a.vis_max_depth = vp.max_depth;
-    a.vis_conf_threshold = c->vis.conf_threshold;
-    a.vis0_f = vp.f0;
-    a.vis0_y = vp.y0;
-  }
   hipStream_t st = c->ls;
   const uint32_t gridS = stream_grid(c, (uint64_t)c->known_surfels + 2 * c->P);
   a.pose_idx = c->timestamp;
@@ -1176,72 +1076,6 @@ hipError_t launch_map_update(suma_ctx* c, const float* pose, const float* inv_po
     else
       k10_generate<false><<<compact_grid(c, P), SUMA_TILE, 0, st>>>(a);
   }
-  return hipGetLastError();
-}
-
-/* ---------------------------------------------------------------------------------------------
- * visibility lists: the flag bytes K9 / K10 left at the surfels' final indices -> two dense index lists
- * ------------------------------------------------------------------------------------------- */
-/* One block per chunk of VIS_CHUNK (2048) flags, 8 per thread (one 8-byte load).  The lists keep the map's chunks
- * apart: chunk c's entries go to list[c * VIS_CHUNK ..] in ascending order and its two counts to cnt0[c] / cnt1[c] -- no
- * block needs another block's count, so there is no atomic, no look-back and no word that every block hits (a first form
- * reserved list space with one atomic per block on one counter: 524 reservations at 1 M surfels, ~90 per microsecond on
- * one word, made it a 12 us kernel); the render passes launch one block per list tile of every chunk and skip the tiles
- * beyond a chunk's count, and the newest surfels still come first (k_render.hip, render_body).
- *   list 0: bit 0 (may pass phase 1a from the update's pose) AND bit 2 (stable)  -- the post-update render
- *   list 1: bit 1 (may pass it from a pose near the predicted next pose)         -- the post-ICP render + K7 splat,
- *           which takes every surfel regardless of stability (gen_indexmap.vert) */
-#define VIS_CHUNK 2048u /* = k_render.hip */
-__global__ void __launch_bounds__(256) k_vis_compact(const uint8_t* __restrict__ flags, const DevState* ds,
-                                                     uint32_t* __restrict__ list0, uint32_t* __restrict__ list1,
-                                                     uint32_t* __restrict__ cnt0, uint32_t* __restrict__ cnt1) {
-  __shared__ uint32_t s_w[4];
-  const uint32_t S = ds->n_surfels;
-  const uint32_t nchunk = (S + VIS_CHUNK - 1u) / VIS_CHUNK;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (uint32_t ch = blockIdx.x; ch < nchunk; ch += gridDim.x) {
-    const uint32_t i0 = ch * VIS_CHUNK + threadIdx.x * 8u;
-    unsigned long long w = 0;
-    if (i0 + 8u <= S) {
-      w = *reinterpret_cast<const unsigned long long*>(flags + i0);
-    } else {
-      for (uint32_t k = 0; k < 8u; ++k)
-        if (i0 + k < S) w |= (unsigned long long)flags[i0 + k] << (8u * k);
-    }
-    const unsigned long long m0 = (w & (w >> 2)) & 0x0101010101010101ull;
-    const unsigned long long m1 = (w >> 1) & 0x0101010101010101ull;
-    const uint32_t packed = (uint32_t)__popcll(m0) | ((uint32_t)__popcll(m1) << 16); /* <= 2048 per chunk: no carry */
-    const uint32_t incl = wave_inclusive_scan(packed);
-    if (lane == 63) s_w[wave] = incl;
-    __syncthreads();
-    uint32_t off = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const uint32_t cw = s_w[k];
-      if (k < wave) off += cw;
-      tot += cw;
-    }
-    if (threadIdx.x == 0) {
-      cnt0[ch] = tot & 0xffffu;
-      cnt1[ch] = tot >> 16;
-    }
-    const uint32_t excl = incl + off - packed;
-    uint32_t r0 = ch * VIS_CHUNK + (excl & 0xffffu), r1 = ch * VIS_CHUNK + (excl >> 16);
-#pragma unroll
-    for (uint32_t k = 0; k < 8u; ++k) {
-      if ((m0 >> (8u * k)) & 1ull) list0[r0++] = i0 + k;
-      if ((m1 >> (8u * k)) & 1ull) list1[r1++] = i0 + k;
-    }
-    __syncthreads(); /* s_w is rewritten by the next chunk */
-  }
-}
-hipError_t launch_vis_compact(suma_ctx* c) {
-  uint64_t blocks = ((uint64_t)c->known_surfels + 2 * c->P + VIS_CHUNK - 1) / VIS_CHUNK;
-  if (blocks > 16384) blocks = 16384;
-  if (blocks < 1) blocks = 1;
-  ProfScope ps(c, "k_vis_compact", 1.0 * (double)c->known_surfels);
-  k_vis_compact<<<(uint32_t)blocks, 256, 0, c->ls>>>(c->vis_flags, c->ds, c->vis_list[0], c->vis_list[1], c->vis_cnt[0],
-                                                    c->vis_cnt[1]);
   return hipGetLastError();
 }
 

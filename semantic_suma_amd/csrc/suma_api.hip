@@ -45,11 +45,6 @@ void rigid_inverse_f(const float* m, float* out) {
   out[15] = 1.0f;
 }
 
-static void eye_d(double* T);
-static void mul4_d(const double* A, const double* B, double* C);
-static void rigid_inv_d(const double* m, double* out);
-static void cast_f(const double* T, float* out);
-
 static float deg2rad_f(float deg) { return (float)((double)deg * M_PI / 180.0); }
 
 /* derived constants exactly as the reference's setParameters() compute them
@@ -243,8 +238,6 @@ static int map_reset_impl(suma_ctx* c) {
   c->extraction.clear();
   c->known_surfels = 0;
   c->map_version++;
-  c->vis.valid = false;
-  c->vis.have_prev = false;
   c->rendered.valid = false;
   c->k7.valid = false;
   c->k8_fused_frame = nullptr; /* the timestamp restarts at 0: a stale (frame, stamp) pair must not match again */
@@ -335,22 +328,6 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
     CK(hipMemsetAsync(c->integrated, 0, P, c->stream));
     CK(hipMalloc((void**)&c->extract_flags, (size_t)params->max_surfels));
     c->flagged.valid = false;
-    /* visibility lists (k_update.hip: visibility bits, k_vis_compact; k_render.hip: list mode) */
-    c->vis_off = getenv("SUMA_NO_VIS_LISTS") != nullptr;
-    c->vis_verify = getenv("SUMA_VIS_VERIFY") != nullptr;
-    c->vis.valid = false;
-    c->vis.have_prev = false;
-    c->vis_params.enabled = 0;
-    c->vis_appends = 0;
-    if (!c->vis_off) {
-      CK(hipMalloc((void**)&c->vis_flags, (size_t)params->max_surfels + 8)); /* k_vis_compact reads 8 bytes at a time */
-      c->vis_chunks_cap = (uint32_t)(((size_t)params->max_surfels + 2047) / 2048 + 1);
-      for (int b = 0; b < 2; ++b) {
-        CK(hipMalloc((void**)&c->vis_list[b], (size_t)c->vis_chunks_cap * 2048 * sizeof(uint32_t)));
-        CK(hipMalloc((void**)&c->vis_cnt[b], (size_t)c->vis_chunks_cap * sizeof(uint32_t)));
-        CK(hipMemsetAsync(c->vis_cnt[b], 0, (size_t)c->vis_chunks_cap * sizeof(uint32_t), c->stream));
-      }
-    }
     CK(hipMalloc((void**)&c->index_map, P * 4));
     CK(hipMemsetAsync(c->index_map, 0, P * 4, c->stream));
     CK(hipMalloc((void**)&c->zbuf_a, Pm * 8));
@@ -453,7 +430,7 @@ extern "C" void suma_ctx_destroy(suma_ctx* c) {
     hipEventDestroy(ev.b);
   }
   for (auto& e : c->prof_pool) hipEventDestroy(e);
-  void* dev[] = {c->vis_flags, c->vis_list[0], c->vis_list[1], c->vis_cnt[0], c->vis_cnt[1], c->extract_flags, c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
+  void* dev[] = {c->extract_flags, c->pose_block, c->pixrec, c->zbuf_data, c->eroded,      c->radius_conf, c->integrated,  c->index_map, c->zbuf_a,
                  c->zbuf_b,    c->surfels[0],  c->surfels[1],  c->poses,       c->poses_inv, c->tile_status, c->tile_group,
                  c->ds,        c->gn,          c->gn_partial,  c->gn_history,  c->gn_T0s,    c->cache_arena,
                  c->cache_slots, c->scan_points, c->scan_labels, c->scan_probs, c->sync_flags, c->zbuf_k1,
@@ -1053,7 +1030,6 @@ static int append_cached(suma_ctx* c, int32_t i, int32_t j) {
   auto it = c->cache_index.find(std::make_pair(i, j));
   if (it == c->cache_index.end()) return SUMA_OK; /* never extracted: an empty SubmapCache */
   CK(launch_append_cached(c, it->second));
-  c->vis_appends += 1; /* records behind the update's stream-out: the visibility lists do not cover them */
   return SUMA_OK;
 }
 
@@ -1122,66 +1098,6 @@ static int update_active_submaps(suma_ctx* c, const float* pose) {
   return SUMA_OK;
 }
 
-/* Visibility lists: what the update at `pose` forms its visibility bits with (k_update.hip, vis_may_pass), and what the two
- * render passes behind it are tested against (k_render.hip, list mode).
- *   list 0 -- a render from `pose` itself (the post-update render, SurfelMapping.cpp:803): the margin only has to absorb
- *             the rounding differences between k9_update's transform (inv_pose * (Ps * p)) and k_render's
- *             ((inv_pose * Ps) * p), a few ulp of the world coordinates;
- *   list 1 -- a render from the NEXT sensor pose (render_active after the next scan's ICP, SurfelMapping.cpp:406, with
- *             the K7 splat): predicted as pose * X0 with X0 = the last increment (previous update's pose^-1 * pose; the
- *             reference starts its ICP there, SurfelMapping.cpp:373-376), margins just outside what the reference still
- *             accepts as a tracked increment (0.4 m / 0.1 rad off the prediction, :438).  A pose outside the margin
- *             -- a lost track, a loop closure -- makes the pass walk the whole map, decided on the device. */
-static void vis_prepare(suma_ctx* c, const float* pose) {
-  VisParams& vp = c->vis_params;
-  vp.enabled = 0;
-  c->vis.valid = false;
-  if (c->vis_off || memcmp(&c->pd, &c->pm, sizeof(proj_t)) != 0) { /* the bits are formed with the data projection */
-    c->vis.have_prev = false;
-    return;
-  }
-  const float mag = fabsf(pose[12]) + fabsf(pose[13]) + fabsf(pose[14]);
-  vp.dt[0] = 0.02f + 2e-5f * mag;
-  vp.dth[0] = 0.01f;
-  vp.dt[1] = 0.45f + 2e-5f * mag;
-  vp.dth[1] = 0.11f;
-  c->vis.lim_dt[0] = 0.5f * vp.dt[0];
-  c->vis.lim_tr[0] = (float)(1.0 + 2.0 * cos(0.004)) + 1e-6f;
-  c->vis.lim_dt[1] = 0.42f + 1e-5f * mag;
-  c->vis.lim_tr[1] = (float)(1.0 + 2.0 * cos(0.105)) + 1e-6f;
-  double Pd[16], X0[16], next[16];
-  for (int i = 0; i < 16; ++i) Pd[i] = (double)pose[i];
-  eye_d(X0);
-  if (c->vis.have_prev) {
-    double prev[16], inv_prev[16];
-    for (int i = 0; i < 16; ++i) prev[i] = (double)c->vis.prev_pose[i];
-    rigid_inv_d(prev, inv_prev);
-    mul4_d(inv_prev, Pd, X0);
-  }
-  mul4_d(Pd, X0, next);
-  memcpy(c->vis.ref[0], pose, 16 * sizeof(float));
-  cast_f(next, c->vis.ref[1]);
-  for (int k = 0; k < 3; ++k) {
-    vp.t0[k] = (float)X0[12 + k];
-    vp.r2[k] = (float)X0[8 + k];
-  }
-  /* elevation inside the image: y01 = 1 - (pitch_deg + fov_up) / fov in [0, 1) <=> -fov_down <= elevation < fov_up */
-  const double lo = -((double)c->pm.fov - (double)c->pm.fov_up) * M_PI / 180.0, hi = (double)c->pm.fov_up * M_PI / 180.0;
-  vp.sin_lo = (float)sin(lo < -M_PI / 2 ? -M_PI / 2 : lo) - 1e-4f;
-  vp.sin_hi = (float)sin(hi > M_PI / 2 ? M_PI / 2 : hi) + 1e-4f;
-  vp.min_depth = c->pm.min_depth - 0.01f;
-  vp.max_depth = c->pm.max_depth + 0.01f;
-  /* bit 0 with constant margins (k9_prepare): direction change of a surfel >= 1 m away under a translation <= dt[0] */
-  if (!(vp.dt[0] < 0.5f) || !(c->pm.fov > 0.0f)) { /* coordinates of 1e4 m and more: float leaves no margin to speak of */
-    c->vis.have_prev = false;
-    return;
-  }
-  vp.f0 = 1.5708f * vp.dt[0] + 1e-3f;
-  vp.y0 = (float)((double)(1.5708f * vp.dt[0] + vp.dth[0] + 1e-3f) * (180.0 / M_PI) / (double)c->pm.fov) + 1e-4f;
-  c->vis.conf_threshold = c->p.confidence_threshold;
-  vp.enabled = 1;
-}
-
 extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_frame* frame) {
   if (c && c->gate_pending) CK(flush_gate(c));
   if (!c || !pose || !frame) return SUMA_ERR_INVALID;
@@ -1238,24 +1154,11 @@ extern "C" int suma_map_update(suma_ctx* c, const float pose[16], const suma_fra
   c->flagged.j = tj;
   c->flagged.fused = fused_slot >= 0;
   c->flagged.slot = fused_slot >= 0 ? (uint32_t)fused_slot : 0u;
-  vis_prepare(c, pose);
   CK(launch_map_update(c, pose, inv_pose, frame, cx, cy, extent, k7_done, flag_tile ? ex : nullptr, fused_slot));
   c->cur ^= 1;
   c->map_version++;
-  const uint32_t appends0 = c->vis_appends;
   int r = update_active_submaps(c, pose);
   if (r) return r;
-  if (c->vis_params.enabled) {
-    if (c->vis_appends == appends0) { /* the map is exactly what K9 / K10 streamed out */
-      CK(launch_vis_compact(c));
-      c->vis.valid = true;
-      c->vis.map_version = c->map_version;
-      c->vis.params_version = c->params_version;
-    }
-    memcpy(c->vis.prev_pose, pose, 16 * sizeof(float));
-    c->vis.have_prev = true;
-    c->vis_params.enabled = 0;
-  }
   c->timestamp += 1;
   return SUMA_OK;
 }
@@ -1386,26 +1289,6 @@ extern "C" int suma_map_size(suma_ctx* c, uint32_t* n) {
   if (r) return r;
   *n = c->h_ds->n_surfels;
   return check_overflow(c);
-}
-extern "C" int suma_debug_vis_stats(suma_ctx* c, uint32_t out[4]) {
-  if (!c || !out) return SUMA_ERR_INVALID;
-  int r = read_state(c);
-  if (r) return r;
-  out[0] = out[1] = 0;
-  if (c->vis.valid && c->vis.map_version == c->map_version && c->vis_cnt[0]) { /* sizes of the lists: sums of the chunk counts */
-    const uint32_t nch = (c->h_ds->n_surfels + 2047u) / 2048u;
-    std::vector<uint32_t> cnt(nch);
-    for (int b = 0; b < 2 && nch; ++b) {
-      CK(hipMemcpyAsync(cnt.data(), c->vis_cnt[b], (size_t)nch * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-      CK(hipStreamSynchronize(c->stream));
-      uint64_t sum = 0;
-      for (uint32_t v : cnt) sum += v;
-      out[b] = (uint32_t)sum;
-    }
-  }
-  out[2] = c->h_ds->vis_violations;
-  out[3] = c->h_ds->vis_list_passes;
-  return SUMA_OK;
 }
 extern "C" int suma_map_timestamp(suma_ctx* c, uint32_t* t) {
   if (!c || !t) return SUMA_ERR_INVALID;

@@ -6,7 +6,6 @@
 #define SUMA_INTERNAL_H_
 
 #include <hip/hip_runtime.h>
-#include <stddef.h>
 #include <stdint.h>
 
 #include <map>
@@ -44,20 +43,7 @@ struct DevState {
   uint32_t cache_used;     /* surfels allocated from the submap cache arena */
   uint32_t fault_site;     /* which bounded spin gave up (bit per site; reported with overflow bit 3) */
   uint32_t n_ext_update;   /* extraction fused into the update: records K9 sent to the cache arena (K10's come behind) */
-  uint32_t pad[2];
-  uint32_t vis_violations; /* SUMA_VIS_VERIFY: candidates of a render pass that their list would have missed (must stay 0) */
-  uint32_t vis_list_passes; /* render launches that walked a list instead of the map (statistics) */
-};
-static_assert(sizeof(DevState) == 64, "DevState layout");
-
-/* visibility bits of an update (k_update.hip, vis_may_pass): filled by suma_map_update (vis_prepare) */
-struct VisParams {
-  int enabled;
-  float dt[2], dth[2];   /* margins of bit 0 / bit 1: translation [m], rotation [rad] */
-  float t0[3], r2[3];    /* predicted increment X0: translation, third column of the rotation */
-  float sin_lo, sin_hi;  /* sines of the lowest / highest elevation inside the image */
-  float min_depth, max_depth;
-  float f0, y0;          /* bit 0 from k9_prepare's own projection: margins of the facing cosine / the image row y01 */
+  uint32_t pad[4];
 };
 
 /* one cached submap tile in the device arena */
@@ -218,27 +204,6 @@ struct suma_ctx {
     uint32_t slot;
   } flagged;
   uint32_t* index_map;                 /* P: K7 winners as surfel id + 1 (exported by K10) */
-  /* Visibility lists (k_update.hip "visibility bits", k_render.hip "list mode").  K9 / K10 leave one byte per surfel of
-   * the compaction target -- bit 0: MAY pass the render passes' phase-1a geometry from the update's pose, bit 1: MAY pass
-   * it from any pose within (vis.dt, vis.dth) of the predicted next pose, bit 2: stable at the update's confidence
-   * threshold -- k_vis_compact turns them into two index lists, and the two render passes that follow walk a list
-   * instead of the whole map when a device-side test finds their pose inside the list's margin (else: the whole map). */
-  uint8_t* vis_flags;                  /* max_surfels */
-  uint32_t* vis_list[2];               /* max_surfels each: the entries of map chunk c at [c * 2048, + vis_cnt[.][c]) */
-  uint32_t* vis_cnt[2];                /* per chunk of 2048 surfels */
-  uint32_t vis_chunks_cap;
-  struct {
-    bool valid;                        /* the lists describe the map (map_version) under params_version */
-    uint64_t map_version, params_version;
-    float ref[2][16];                  /* reference pose of list 0 (the update's pose) / list 1 (the predicted next pose) */
-    float lim_dt[2], lim_tr[2];        /* what k_render tests a pass's pose against (inside the margins of the bits) */
-    float conf_threshold;              /* bit 2 was formed against this threshold */
-    bool have_prev;                    /* prev_pose = pose of the previous update (prediction: constant increment) */
-    float prev_pose[16];
-  } vis;
-  int vis_off, vis_verify;             /* SUMA_NO_VIS_LISTS / SUMA_VIS_VERIFY (read once at creation) */
-  VisParams vis_params;                /* what the update being enqueued forms its visibility bits with */
-  uint32_t vis_appends;                /* cached tiles appended so far (an update followed by one leaves no valid lists) */
   unsigned long long* tile_status;     /* look-back status words */
   unsigned long long* tile_group;      /* 2 x group_words, per 64 tiles: {arrived, sum}; launches alternate halves */
   uint32_t group_words;
@@ -401,8 +366,6 @@ hipError_t launch_set_poses(suma_ctx* c, const float* d_src, uint32_t first, uin
 hipError_t launch_fill_identity_poses(suma_ctx* c);
 hipError_t launch_extract(suma_ctx* c, uint32_t slot, float cx, float cy, float extent, int use_flags);
 hipError_t launch_append_cached(suma_ctx* c, uint32_t slot);
-/* flags of the update that has just run -> the two visibility lists + DevState.n_vis (one launch) */
-hipError_t launch_vis_compact(suma_ctx* c);
 
 /* k_sync.hip: in-memory hand-offs between the ctx stream and the side stream.  A runtime event dependency between two
  * HIP streams costs ~10 us of stall on this platform (tools/xstream.hip: ping-pong 42 us vs 22 us for the same two

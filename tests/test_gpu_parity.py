@@ -880,59 +880,6 @@ def test_native_scan_loop_equals_scan_by_scan_calls(hip):
     assert a.runScans([], True) == 0
 
 
-def _run_sequence(hip, width, ks, env):
-    """a fresh pipeline over the scans ks with `env` set while its context is created (the switches are read there)"""
-    saved = {k: os.environ.get(k) for k in ("SUMA_NO_VIS_LISTS", "SUMA_VIS_VERIFY")}
-    for k in saved:
-        os.environ.pop(k, None)
-    os.environ.update(env)
-    try:
-        q = hip.SurfelMapping(params_with_size(width))
-    finally:
-        for k, v in saved.items():
-            os.environ.pop(k, None)
-            if v is not None:
-                os.environ[k] = v
-    poses, idx = [], []
-    for k in ks:
-        q.processScan(*get_scan(k, width, True)[:3], fixed_iterations=10)
-        poses.append(q.getCurrentPose().copy())
-        idx.append(q.map.index_map().copy())
-    return q, poses, idx
-
-
-def test_visibility_lists_are_supersets(hip):
-    """SUMA_VIS_VERIFY: the render passes walk the whole map and check every surfel that survives their phase 1a
-    (render_surfels.geom:76-103, gen_indexmap.vert:62-81) against the flag byte the update left for it -- a survivor
-    whose flags would have kept it off the pass's list is a violation.  None on a live sequence, including a jump in
-    the motion (pose outside the margin: the pass does not count as a list pass) -- and the pose test must hold on
-    the ordinary scans, or the lists would never be used."""
-    ks = list(range(0, 40)) + [43, 44, 45, 46]
-    q, _, _ = _run_sequence(hip, 900, ks, {"SUMA_VIS_VERIFY": "1"})
-    st = q.ctx.vis_stats()
-    assert st["violations"] == 0, st
-    assert st["list_passes"] >= 2 * (len(ks) - 8), st  # two render passes per scan found their pose inside the margin
-    assert 0 < st["list0"] < q.map.size() and 0 < st["list1"] < q.map.size(), (st, q.map.size())
-
-
-def test_visibility_lists_change_nothing(hip):
-    """the same sequence with the lists (default) and without (SUMA_NO_VIS_LISTS): pose bits, index maps, the whole
-    surfel buffer and the three model frames are equal after every scan; with the lists the passes did walk them"""
-    ks = list(range(0, 30)) + [33, 34, 35]
-    a, pa, ia = _run_sequence(hip, 900, ks, {})
-    b, pb, ib = _run_sequence(hip, 900, ks, {"SUMA_NO_VIS_LISTS": "1"})
-    for n in range(len(ks)):
-        assert np.array_equal(pa[n], pb[n]), f"scan {n}: pose bits"
-        assert np.array_equal(ia[n], ib[n]), f"scan {n}: index map"
-    assert a.map.getAllSurfels().tobytes() == b.map.getAllSurfels().tobytes()
-    for w in (0, 1, 2):
-        for m in range(3):
-            assert_bit_equal(a.frame(w).download(m), b.frame(w).download(m), f"frame {w} map {m}")
-    sa, sb = a.ctx.vis_stats(), b.ctx.vis_stats()
-    assert sa["list_passes"] >= 2 * (len(ks) - 8) and sb["list_passes"] == 0, (sa, sb)
-    assert a.trackLoss() == b.trackLoss() and a.trackLoss() >= 1, "the sequence was meant to trip the fallback once"
-
-
 _GATHER_SCRIPT = r"""
 import ctypes as C, os, sys
 import numpy as np
