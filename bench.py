@@ -76,6 +76,18 @@ def cached_scan(k, W, H):
     return pts, lab, prob
 
 
+def usable_cpus():
+    """CPUs this process may really use: the cgroup quota (cpu.max) where there is one, else the visible cores"""
+    n = os.cpu_count() or 1
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _gen_job(args):
     k, W, H = args
     return k, cached_scan(k, W, H)
@@ -85,7 +97,9 @@ def generate_scans(ks, W, H):
     """synthetic scans for the indices ks (in order); long runs (the literal 4541-scan sequence) are generated by a pool
     of worker processes -- one scan is ~25 ms of single-threaded numpy"""
     ks = list(ks)
-    workers = min(32, max(1, (os.cpu_count() or 2) // 4))
+    # every rank of an N-GPU run generates its own stretch at the same time: the host's CPUs (what the cgroup grants, not
+    # what the box shows -- the pool's boxes show 256 cores and grant 16) are shared between the ranks' pools
+    workers = min(32, max(1, usable_cpus() // max(1, int(os.environ.get("WORLD_SIZE", "1")))))
     if len(ks) < 400 or workers < 2:
         for k in ks:
             yield cached_scan(k, W, H)
