@@ -193,15 +193,6 @@ int suma_pipeline_process_scan(suma_pipeline* s, const suma_float4* points, cons
                                uint32_t n, int32_t fixed_iterations);
 int suma_pipeline_process_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
                                       const float* d_probs, uint32_t n, int32_t fixed_iterations);
-/* The same, for a caller that already holds the NEXT scan in device memory (a recorded sequence: suma_pipeline_run_scans):
- * the next scan's preprocessing (Preprocessing::process, K1-K3) is enqueued on the side stream now and runs beside this
- * scan's Gauss-Newton chain; the next call, which must pass exactly the next_* buffers (same pointers, same n), finds its
- * frame made.  Same kernels on the same inputs, only earlier: results are bit-identical to scan-by-scan calls.  A next
- * call with other buffers preprocesses as always.  SUMA_NO_LOOKAHEAD=1 switches it off. */
-int suma_pipeline_process_scan_device_ahead(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                                            const float* d_probs, uint32_t n, int32_t fixed_iterations,
-                                            const suma_float4* next_points, const float* next_labels, const float* next_probs,
-                                            uint32_t next_n);
 /* ---- device-side scan ingest (KITTIReader::read hands over host vectors, KITTIReader.cpp:136-203 ->
  *      SurfelMapping::processScan(const rv::Laserscan&), SurfelMapping.cpp:175): three pinned staging slots, a copy
  *      stream and an ingest thread.  prefetch stages the scan (host copy into pinned memory + async H2D, both off

@@ -47,9 +47,7 @@ typedef struct suma_sequence_result {
  * (VisualizerWindow.cpp:636-689 -> SurfelMapping.cpp:175).  This is that loop on an EXISTING pipeline: the next
  * job->n_scans scans of its sequence, without a reset and without a stream synchronisation at the end (the pipeline
  * stays as asynchronous as after a single suma_pipeline_process_scan* call).  Host arrays take the blocking host-vector
- * entry (no look-ahead); device arrays the resident entry, and since the loop holds the whole stretch it hands every scan
- * over together with its successor (suma_pipeline_process_scan_device_ahead: the successor's preprocessing runs beside
- * this scan's Gauss-Newton chain; bit-identical results).  *scans_done = scans that went through. */
+ * entry (no look-ahead), device arrays the resident entry.  *scans_done = scans that went through. */
 int suma_pipeline_run_scans(suma_pipeline* pipeline, const suma_sequence_job* job, int32_t fixed_iterations,
                             uint32_t* scans_done, double* seconds_per_call /* NULL, or n_scans host times: a stall of the
                             calling thread or of a copy helper shows up as ONE long call */);

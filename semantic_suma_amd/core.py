@@ -163,7 +163,6 @@ def lib():
     L.suma_pipeline_ctx.argtypes = [vp]
     L.suma_pipeline_process_scan.argtypes = [vp, vp, vp, vp, u32, i32]
     L.suma_pipeline_process_scan_device.argtypes = [vp, vp, vp, vp, u32, i32]
-    L.suma_pipeline_process_scan_device_ahead.argtypes = [vp, vp, vp, vp, u32, i32, vp, vp, vp, u32]
     L.suma_pipeline_pose.argtypes = [vp, vp]
     L.suma_pipeline_begin_scan.argtypes = [vp, vp, vp, vp, u32]
     L.suma_pipeline_begin_scan_device.argtypes = [vp, vp, vp, vp, u32]
@@ -841,14 +840,6 @@ class SurfelMapping:
         self.ctx.check(self.L.suma_pipeline_process_scan_device(self.h, C.c_void_p(d_points), C.c_void_p(d_labels),
                                                                 C.c_void_p(d_probs), n, fixed_iterations),
                        "suma_pipeline_process_scan_device")
-
-    def processScanDeviceAhead(self, scan, next_scan, fixed_iterations: int = 0):
-        """scan = (d_points, d_labels, d_probs, n) resident in HBM, processed now; next_scan likewise: its preprocessing
-        is enqueued beside this scan's Gauss-Newton chain, and the next call must pass exactly these buffers (suma_hip.h)"""
-        a, b = scan, next_scan
-        self.ctx.check(self.L.suma_pipeline_process_scan_device_ahead(
-            self.h, C.c_void_p(a[0]), C.c_void_p(a[1]), C.c_void_p(a[2]), a[3], fixed_iterations,
-            C.c_void_p(b[0]), C.c_void_p(b[1]), C.c_void_p(b[2]), b[3]), "suma_pipeline_process_scan_device_ahead")
 
     def prefetchScan(self, points, labels=None, probs=None):
         """stage a scan (pinned copy + async upload on the ingest thread / copy stream); the arrays are kept alive

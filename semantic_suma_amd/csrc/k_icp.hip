@@ -384,12 +384,6 @@ struct IterArgs {
   /* eval-only pixel launch that reports by itself (last block), see the end of icp_iter_body */
   HostResult* fused_report;
   uint32_t* fused_counter;
-  /* optional: a sequence word this launch stores when it STARTS (block 0, thread 0).  The scan pipeline's native loop puts
-   * the next scan's preprocessing on the side stream behind a gate on this word (suma_api.hip, pipeline_preprocess_ahead):
-   * K1-K3 then run beside this chain, which leaves most of the chip idle, instead of beside the previous scan's render and
-   * update passes, which do not (profiles/r05_second_session_experiments.txt, item 4) */
-  uint32_t* start_word;
-  uint32_t start_seq;
 };
 
 /* One launch of the Gauss-Newton chain.  grid = (nblocks or 1, n_hyp).
@@ -423,8 +417,6 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
   __shared__ double s_pose[16], s_E[16], s_val[SUMA_ACC_WORDS];
   __shared__ uint32_t s_flag[4]; /* done, iteration, history slot, last-block flag */
 
-  if (g.start_word != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-    __hip_atomic_store(g.start_word, g.start_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (blockIdx.x == 0 && threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) /* for the next launch */
     for (uint32_t h = blockIdx.y; h < g.zero_hyp; h += gridDim.y)
       g.pzero[(size_t)h * ICP_RECORDS * SUMA_ACC_WORDS + threadIdx.x] = 0;
@@ -1014,9 +1006,6 @@ hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, 
   g.ds = c->ds;
   g.fused_report = (pixel && eval_only && n_hyp == 1) ? c->gn_fused_report : nullptr;
   g.fused_counter = &c->ds->reserved0;
-  g.start_word = c->gn_start_word; /* consumed by the first launch enqueued after it was set */
-  g.start_seq = c->gn_start_seq;
-  c->gn_start_word = nullptr;
   g.init = c->gn_init_pending;
   g.iteration0 = c->gn_iteration0;
   for (int i = 0; i < 16; ++i) g.T0.m[i] = c->gn_T0_host[i];

@@ -74,11 +74,6 @@ void side_stream_released(suma_ctx* c) {
   if (c->side_stream) g_side_ctxs.fetch_sub(1);
 }
 
-bool side_inmemory_ok() {
-  static const bool force_events = getenv("SUMA_GATE_EVENTS") != nullptr;
-  return !force_events && g_side_ctxs.load() <= 1;
-}
-
 int side_handoff(suma_ctx* c, const suma_frame* frame) {
   static const bool force_events = getenv("SUMA_GATE_EVENTS") != nullptr;
   c->pre_seq += 1;

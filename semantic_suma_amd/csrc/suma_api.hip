@@ -802,10 +802,7 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
 static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history) {
   const uint32_t max_iter = c->p.max_iterations;
   const uint32_t iter_arg = max_iter > 0 ? max_iter : 0xffffffffu;
-  /* the chain reads the frame the side stream preprocessed (k_sync.hip).  Only THAT hand-off is waited for: a pending
-   * hand-off of another frame is the next scan's look-ahead preprocessing, which itself waits for this chain to start */
-  if (c->gate_pending && (c->gate_frame == nullptr || c->gate_frame == c->icp_current || c->gate_frame == c->icp_model))
-    CK(flush_gate(c));
+  if (c->gate_pending) CK(flush_gate(c)); /* the chain reads the frame the side stream preprocessed (k_sync.hip) */
   accessed(c, c->icp_current);
   accessed(c, c->icp_model);
   if (with_history) c->hist_seq += 1; /* this chain overwrites the device-side pose history */
@@ -1578,10 +1575,9 @@ extern "C" int suma_pipeline_create(const suma_params* params, int hip_device, s
   }
   memset(s, 0, sizeof(*s));
   s->c = c;
-  /* next_frame: the third data frame of the look-ahead preprocessing (pipeline_preprocess_ahead) */
-  suma_frame** fr[5] = {&s->last_frame, &s->current_frame, &s->current_model, &s->last_model, &s->next_frame};
-  for (int k = 0; k < 5; ++k) {
-    bool data = k < 2 || k == 4;
+  suma_frame** fr[4] = {&s->last_frame, &s->current_frame, &s->current_model, &s->last_model};
+  for (int k = 0; k < 4; ++k) {
+    bool data = k < 2;
     r = frame_create_raw(c, data ? params->data_width : params->model_width,
                          data ? params->data_height : params->model_height, fr[k]);
     if (r) {
@@ -1624,7 +1620,6 @@ extern "C" void suma_pipeline_destroy(suma_pipeline* s) {
   if (s->c && s->c->stream) hipStreamSynchronize(s->c->stream);
   suma_frame_destroy(s->last_frame);
   suma_frame_destroy(s->current_frame);
-  suma_frame_destroy(s->next_frame);
   suma_frame_destroy(s->current_model);
   suma_frame_destroy(s->last_model);
   if (s->h_res) hipHostFree(s->h_res);
@@ -1845,27 +1840,8 @@ int pipeline_begin_scan_impl(suma_pipeline* s, const suma_float4* d_points, cons
   if (s->phase != 0) return fail(c, SUMA_ERR_INVALID, "suma_pipeline_begin_scan: the previous scan has not been closed with suma_pipeline_update_map");
   c->obj_set = false; /* the pipeline's objective_ runs on the ctx parameters (suma_params), not on a stale adapter object's */
   /* initialize(), SurfelMapping.cpp:323-331 */
-  const bool ahead = s->ahead.valid && s->ahead.points == d_points && s->ahead.labels == d_labels &&
-                     s->ahead.probs == d_probs && s->ahead.n == n && s->ahead.timestamp == s->timestamp && !upload_done;
-  s->ahead.valid = false;
-  std::swap(s->last_model, s->current_model);
-  if (ahead) {
-    /* K1-K3 of THIS scan were enqueued on the side stream while the previous scan was processed
-     * (pipeline_preprocess_ahead) and wrote next_frame; its hand-off is pending or already flushed.  Three frames rotate:
-     * the previous scan's becomes the last one, and the buffer of the one before it is free for the next look-ahead */
-    suma_frame* freed = s->last_frame;
-    s->last_frame = s->current_frame;
-    s->current_frame = s->next_frame;
-    s->next_frame = freed;
-    float po[16], pn[16];
-    cast_f(s->pose_old, po);
-    cast_f(s->pose_new, pn);
-    int ra = map_render_dedup(c, po, pn, conf_threshold(s), s->last_model);
-    if (ra) return ra;
-    s->phase = 1;
-    return SUMA_OK;
-  }
   std::swap(s->last_frame, s->current_frame);
+  std::swap(s->last_model, s->current_model);
   /* preprocess(), :342-358.  K1-K3 of this scan go to the side stream: the host is ahead of the GPU here (the
    * surfel passes of the previous scan are still running on the ctx stream), so they overlap that tail instead of
    * queueing behind it.  Buffers: the frame written here was last read by work the host has already waited for (the
@@ -1923,75 +1899,13 @@ int pipeline_update_map_impl(suma_pipeline* s) {
 
 hipStream_t pipeline_input_stream(suma_pipeline* s) { return s->c->side_stream ? s->c->side_stream : s->c->stream; }
 
-/* Look-ahead preprocessing: K1-K3 of the NEXT scan (resident in HBM) onto the side stream, NOW -- between begin_scan and
- * update_pose of the current scan -- but held behind a gate that the current scan's Gauss-Newton chain opens with its first
- * launch (IterArgs.start_word).  The chain keeps the chip 17 % busy for ~125 us; the preprocessing used to run beside the
- * previous scan's render / update passes instead and cost them 8-9 us per scan (profiles/r05_second_session_experiments.txt).
- * The reference preprocesses a scan when it is handed over (SurfelMapping.cpp:342-358): same kernels, same inputs, same
- * frame contents -- only earlier.  The caller promises that the next processScan call passes exactly these buffers; a call
- * that passes others simply preprocesses as always.  Needs the in-memory stream hand-off (one pipeline in the process). */
-static int pipeline_preprocess_ahead(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                                     const float* d_probs, uint32_t n) {
-  suma_ctx* c = s->c;
-  static const bool off = getenv("SUMA_NO_LOOKAHEAD") != nullptr;
-  if (off || !c->side_stream || !side_inmemory_ok() || (n > 0 && !d_points)) return SUMA_OK;
-  if (!s->next_frame) return SUMA_OK;
-  /* the hand-off of the CURRENT scan's frame goes onto the ctx stream before a new one takes its place */
-  if (c->gate_pending) CK(flush_gate(c));
-  s->ahead_seq += 1;
-  if (s->timestamp > 0) { /* update_pose follows: its first launch opens the gate (scan 0 has no chain: start at once) */
-    CK(launch_gate(c, c->side_stream, 1, s->ahead_seq));
-    c->gn_start_word = c->sync_flags + 1;
-    c->gn_start_seq = s->ahead_seq;
-    s->ahead_armed = true;
-  }
-  c->ls = c->side_stream;
-  int r = suma_preprocess_device(c, d_points, d_labels, d_probs, n, s->timestamp + 1, s->next_frame);
-  c->ls = c->stream;
-  if (r == SUMA_OK) r = side_handoff(c, s->next_frame);
-  if (r) return r;
-  s->ahead.valid = true;
-  s->ahead.points = d_points;
-  s->ahead.labels = d_labels;
-  s->ahead.probs = d_probs;
-  s->ahead.n = n;
-  s->ahead.timestamp = s->timestamp + 1;
-  return SUMA_OK;
-}
-/* the gate of a look-ahead whose chain was never launched (an error in front of it) must not be left waiting */
-static void pipeline_release_ahead(suma_pipeline* s) {
-  suma_ctx* c = s->c;
-  if (s->ahead_armed && c->gn_start_word != nullptr) {
-    launch_signal(c, c->stream, 1, s->ahead_seq);
-    c->gn_start_word = nullptr;
-  }
-  s->ahead_armed = false;
-}
-
-static int pipeline_process_scan_ahead_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                                            const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done,
-                                            const suma_float4* next_points, const float* next_labels, const float* next_probs,
-                                            uint32_t next_n, bool have_next) {
+int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
+                               const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done) {
   int r = pipeline_begin_scan_impl(s, d_points, d_labels, d_probs, n, upload_done);
-  if (r == SUMA_OK && have_next) r = pipeline_preprocess_ahead(s, next_points, next_labels, next_probs, next_n);
   if (r == SUMA_OK) r = pipeline_update_pose_impl(s, fixed_iterations);
-  if (s) pipeline_release_ahead(s);
   if (r == SUMA_OK) r = pipeline_update_map_impl(s);
   if (r != SUMA_OK && s) s->phase = 0; /* a failed scan does not wedge the phase check */
   return r;
-}
-int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                               const float* d_probs, uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done) {
-  return pipeline_process_scan_ahead_impl(s, d_points, d_labels, d_probs, n, fixed_iterations, upload_done, nullptr, nullptr,
-                                          nullptr, 0, false);
-}
-extern "C" int suma_pipeline_process_scan_device_ahead(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
-                                                       const float* d_probs, uint32_t n, int32_t fixed_iterations,
-                                                       const suma_float4* next_points, const float* next_labels,
-                                                       const float* next_probs, uint32_t next_n) {
-  if (!s) return SUMA_ERR_INVALID;
-  return pipeline_process_scan_ahead_impl(s, d_points, d_labels, d_probs, n, fixed_iterations, nullptr, next_points, next_labels,
-                                          next_probs, next_n, true);
 }
 
 extern "C" int suma_pipeline_begin_scan_device(suma_pipeline* s, const suma_float4* d_points, const float* d_labels,
@@ -2019,7 +1933,6 @@ extern "C" int suma_pipeline_reset(suma_pipeline* s) {
   s->timestamp = 0;
   s->track_loss = 0;
   s->phase = 0;
-  s->ahead.valid = false; /* a frame preprocessed ahead belongs to the sequence that ended */
   eye_d(s->current_pose);
   eye_d(s->last_pose);
   eye_d(s->pose_old);

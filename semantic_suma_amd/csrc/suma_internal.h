@@ -173,8 +173,6 @@ struct suma_ctx {
   int gn_emit_pose;        /* the closing launch of the chain being enqueued writes pose_block */
   double gn_pose_base[16];
   float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
-  uint32_t* gn_start_word; /* if set: the next Gauss-Newton launch stores gn_start_seq there when it starts (IterArgs) */
-  uint32_t gn_start_seq;
   int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
   uint32_t gn_iteration0;
   double gn_T0_host[16];
@@ -268,18 +266,6 @@ struct suma_ctx {
 struct suma_pipeline {
   suma_ctx* c;
   suma_frame *last_frame, *current_frame, *current_model, *last_model;
-  /* look-ahead preprocessing (pipeline_preprocess_ahead): the NEXT scan's K1-K3, enqueued on the side stream while this
-   * scan is processed, write next_frame (created on first use); begin_scan of that scan rotates the three frames instead
-   * of preprocessing.  ahead_seq numbers the start gates; ahead_armed: a gate is waiting for this scan's chain to start */
-  suma_frame* next_frame;
-  struct {
-    bool valid;
-    const suma_float4* points;
-    const float *labels, *probs;
-    uint32_t n, timestamp;
-  } ahead;
-  uint32_t ahead_seq;
-  bool ahead_armed;
   double current_pose[16], last_pose[16], pose_old[16], pose_new[16], last_increment[16];
   double last_pose_old[16]; /* lastPose_old_, SurfelMapping.cpp:456 */
   uint32_t timestamp;
@@ -298,8 +284,6 @@ struct suma_pipeline {
 
 int pipeline_process_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
                                uint32_t n, int32_t fixed_iterations, hipEvent_t upload_done);
-/* k_sync.hip: may this context hand work between its streams through memory words (one pipeline in the process)? */
-bool side_inmemory_ok();
 int pipeline_begin_scan_impl(suma_pipeline* s, const suma_float4* d_points, const float* d_labels, const float* d_probs,
                              uint32_t n, hipEvent_t upload_done);
 int pipeline_update_pose_impl(suma_pipeline* s, int32_t fixed_iterations);

@@ -67,15 +67,8 @@ extern "C" int suma_pipeline_run_scans(suma_pipeline* s, const suma_sequence_job
   double t_prev = seconds_per_call ? now_s() : 0.0;
   for (; k < job->n_scans && r == SUMA_OK; ++k) {
     const suma_scan_ref& sc = job->scans[k];
-    if (job->on_device && k + 1 < job->n_scans) {
-      /* the next scan is in HBM already: its preprocessing goes beside this scan's Gauss-Newton chain (suma_hip.h) */
-      const suma_scan_ref& nx = job->scans[k + 1];
-      r = suma_pipeline_process_scan_device_ahead(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations, nx.points, nx.labels,
-                                                  nx.probs, nx.n);
-    } else {
-      r = job->on_device ? suma_pipeline_process_scan_device(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations)
-                         : suma_pipeline_process_scan(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations);
-    }
+    r = job->on_device ? suma_pipeline_process_scan_device(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations)
+                       : suma_pipeline_process_scan(s, sc.points, sc.labels, sc.probs, sc.n, fixed_iterations);
     if (seconds_per_call) {
       const double t = now_s();
       seconds_per_call[k] = t - t_prev;

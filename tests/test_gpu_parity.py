@@ -880,48 +880,6 @@ def test_native_scan_loop_equals_scan_by_scan_calls(hip):
     assert a.runScans([], True) == 0
 
 
-def test_lookahead_preprocessing_changes_nothing(hip):
-    """suma_pipeline_process_scan_device_ahead / the native loop over resident scans: the next scan's K1-K3 run beside this
-    scan's Gauss-Newton chain into a third data frame.  Same poses, statistics, index maps and map bytes as scan-by-scan
-    calls -- across a jump in the motion (the fallback minimisation reads the PREVIOUS scan's frame while the next
-    scan's is being written), with a promise that is not kept (another scan follows than the one announced), and with
-    scan-by-scan calls mixed in."""
-    width, ks = 900, [0, 1, 2, 3, 6, 7, 8, 9]
-    p = params_with_size(width)
-    scans_ = [get_scan(k, width, True)[:3] for k in ks]
-    ref = hip.SurfelMapping(p)
-    ref_pose, ref_idx = [], []
-    for sc in scans_:
-        ref.processScan(*sc, fixed_iterations=10)
-        ref_pose.append(ref.getCurrentPose().copy())
-        ref_idx.append(ref.map.index_map().copy())
-    assert ref.trackLoss() >= 1, "the sequence was meant to trip the fallback"
-    # (a) the native loop in one go
-    a = hip.SurfelMapping(p)
-    dev = [tuple(a.ctx.device_array(x) for x in sc) + (sc[0].shape[0],) for sc in scans_]
-    assert a.runScans(dev, True, fixed_iterations=10) == len(ks)
-    # (b) scan by scan with look-ahead, a broken promise at scan 2 (announces scan 5, scan 3 follows) and a plain call
-    b = hip.SurfelMapping(p)
-    devb = [tuple(b.ctx.device_array(x) for x in sc) + (sc[0].shape[0],) for sc in scans_]
-    for n in range(len(ks)):
-        if n == 2:
-            b.processScanDeviceAhead(devb[n], devb[5], fixed_iterations=10)
-        elif n == 4 or n + 1 == len(ks):
-            b.processScanDevice(*devb[n], fixed_iterations=10)
-        else:
-            b.processScanDeviceAhead(devb[n], devb[n + 1], fixed_iterations=10)
-        assert np.array_equal(b.getCurrentPose(), ref_pose[n]), f"scan {n}: pose bits"
-        assert np.array_equal(b.map.index_map(), ref_idx[n]), f"scan {n}: index map"
-    for q in (a, b):
-        assert np.array_equal(q.getCurrentPose(), ref.getCurrentPose())
-        assert q.trackLoss() == ref.trackLoss()
-        assert q.lastStats().as_dict() == ref.lastStats().as_dict()
-        assert q.map.getAllSurfels().tobytes() == ref.map.getAllSurfels().tobytes()
-        for w in (0, 1, 2):
-            for m in range(3):
-                assert_bit_equal(q.frame(w).download(m), ref.frame(w).download(m), f"frame {w} map {m}")
-
-
 _GATHER_SCRIPT = r"""
 import ctypes as C, os, sys
 import numpy as np

@@ -112,34 +112,10 @@ def check(args, p, N, workers):
     keys = [str(k) for k in z["stat_keys"]]
     sha_at = {int(k): i for i, k in enumerate(z["sha_idx"])}
     origins, max_map, compared, t_hip, t0 = set(), 0, 0, 0.0, time.time()
-    # Both entries of the pipeline, in alternating stretches of 200 scans: the blocking host-vector entry
-    # (suma_pipeline_process_scan) and the resident entry WITH look-ahead (suma_pipeline_process_scan_device_ahead: the next
-    # scan's preprocessing beside this scan's Gauss-Newton chain -- what bench.py's timed region runs through the native
-    # loop); the switches between the stretches run the transitions (a look-ahead nobody takes up, a scan without one)
-    dev = {}  # scan index -> device arrays of the look-ahead stretches
-
-    def resident(j, sc):
-        if j not in dev:
-            dev[j] = tuple(hp.ctx.device_array(x) for x in sc) + (sc[0].shape[0],)
-        return dev[j]
-
     with ProcessPoolExecutor(workers) as pool:
-        it = scans_ahead(pool, N, workers)
-        nxt = next(it, None)
-        while nxt is not None:
-            (k, (pts, lab, prob)), nxt = nxt, next(it, None)
+        for k, (pts, lab, prob) in scans_ahead(pool, N, workers):
             t = time.perf_counter()
-            if (k // 200) % 2 == 1:
-                cur = resident(k, (pts, lab, prob))
-                if nxt is not None and (nxt[0] // 200) % 2 == 1:
-                    hp.processScanDeviceAhead(cur, resident(nxt[0], nxt[1]), fixed_iterations=10)
-                else:
-                    hp.processScanDevice(*cur, fixed_iterations=10)
-                for j in [j for j in dev if j < k]:  # the previous scan's buffers are no longer read by anything enqueued
-                    for a in dev.pop(j)[:3]:
-                        hp.ctx.device_free(a)
-            else:
-                hp.processScan(pts, lab, prob, fixed_iterations=10)
+            hp.processScan(pts, lab, prob, fixed_iterations=10)
             pose = hp.getCurrentPose()
             t_hip += time.perf_counter() - t
             assert np.array_equal(pose, z["poses"][k]), f"scan {k}: pose bits"
@@ -160,7 +136,6 @@ def check(args, p, N, workers):
                    "oracle's recorded trace: pose bits, statistics, counters of every scan; SHA-256 of the whole surfel buffer)",
            "scans": N, "width": W, "height": H, "pose_and_statistics_compared": N, "surfel_buffers_compared": compared,
            "submap_origins_visited": len(origins), "max_map_surfels": max_map, "max_surfels_capacity": args.max_surfels,
-           "entries": "stretches of 200 scans alternate between the host-vector entry and the resident entry with look-ahead preprocessing",
            "track_loss_scans": hp.trackLoss(), "drift_m_vs_ground_truth": round(drift, 3),
            "laps_of_the_synthetic_loop": round(N * 1.1 / (2 * 450.0 + 2 * np.pi * 12.0), 2),
            "kernel_source_sha": kernel_source_sha(), "oracle_source_sha_of_the_trace": str(z["oracle_source_sha"]),
