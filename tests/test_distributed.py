@@ -254,3 +254,21 @@ def test_bench_refuses_a_world_size_other_than_gpus():
                          capture_output=True, timeout=300)
     assert res.returncode != 0
     assert b"--gpus 4 but the launcher started WORLD_SIZE=2" in res.stderr
+
+
+def test_bench_scan_generation_pool_is_shared_between_the_ranks(monkeypatch):
+    """bench.py generates a rank's synthetic scans with a pool of worker processes; N ranks of one node do that at the
+    same time, so a rank's pool is what the cgroup grants (not what the box shows) divided by the ranks of the job"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("suma_bench_pool", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    n = bench.usable_cpus()
+    assert 1 <= n <= (os.cpu_count() or 1)
+    # the generator yields the scans in order whatever the pool size (short stretch: generated in-process)
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    ks = [3, 4, 5]
+    out = list(bench.generate_scans(ks, 180, 16))
+    assert len(out) == 3 and all(o[0].shape[1] == 4 for o in out)
+    from semantic_suma_amd import synth
+    assert np.array_equal(out[1][0], synth.generate_scan(4, n_azimuth=180, height=16)[0])
