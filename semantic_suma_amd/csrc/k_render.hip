@@ -68,10 +68,21 @@ struct rvtx {
   float z, tu, tv;
 };
 
-/* edge function of the directed edge a->b at point (px, py), exact in 64-bit integers */
-__device__ __forceinline__ long long edge_fn(const rvtx& a, const rvtx& b, int32_t px, int32_t py) {
-  return (long long)(b.X - a.X) * (long long)(py - a.Y) - (long long)(b.Y - a.Y) * (long long)(px - a.X);
+/* Edge function of the directed edge a->b at point (px, py): an exact integer below 2^47 in magnitude (the four
+ * differences are below 2^23).  Formed in binary64: each product of two such integers is exact (46 bits), and the fused
+ * multiply-add delivers their exact difference (representable, so its one rounding rounds nothing) -- the same integer
+ * the 64-bit form (b.X - a.X) * (py - a.Y) - (b.Y - a.Y) * (px - a.X) computes, as a double.  Why: the 64-bit form costs
+ * two 32 x 32 -> 64-bit multiplies, add-with-carry pairs and 64-bit compares per edge, and its conversion to float is a
+ * dozen instructions (count leading zeros, shifts, rounding) where v_cvt_f32_f64 is one; binary64 issues at the ordinary
+ * VALU rate on gfx950 (profiles/r05_instr_rate_gfx950.txt).  Per pair of pixel tests 831 -> 684 VALU instructions; the
+ * pass is 5 % faster where it is issue-bound (50 M surfels) and unchanged at the steady 1 M map
+ * (profiles/r05_second_session_experiments.txt).  The one value the integer form cannot produce is -0 (two zero products
+ * of unlike sign): comparisons do not see it, and edge_to_float() turns it into the +0 an integer 0 converts to. */
+__device__ __forceinline__ double edge_fn(const rvtx& a, const rvtx& b, int32_t px, int32_t py) {
+  const double ux = (double)(b.X - a.X), uy = (double)(b.Y - a.Y), vx = (double)(px - a.X), vy = (double)(py - a.Y);
+  return __builtin_fma(ux, vy, -(uy * vx));
 }
+__device__ __forceinline__ float edge_to_float(double w) { return (float)(w + 0.0); } /* (float)(long long): -0 -> +0 */
 /* ownership of a pixel centre exactly on an edge: antisymmetric in the edge direction, so a
  * pixel on the diagonal shared by the two strip triangles is produced exactly once */
 __device__ __forceinline__ bool owns_edge(const rvtx& s, const rvtx& t) {
@@ -94,7 +105,7 @@ __device__ __forceinline__ unsigned long long render_key(uint32_t z24, uint32_t 
  * pixel only, so the work can be distributed freely over lanes. */
 __device__ __forceinline__ unsigned long long raster_key(rvtx A, rvtx B, rvtx C, int32_t i, int32_t j, uint32_t id,
                                                          int tie) {
-  long long area = edge_fn(A, B, C.X, C.Y);
+  double area = edge_fn(A, B, C.X, C.Y);
   if (area < 0) {
     rvtx t = B;
     B = C;
@@ -102,21 +113,22 @@ __device__ __forceinline__ unsigned long long raster_key(rvtx A, rvtx B, rvtx C,
     area = -area;
   }
   const int32_t px = 256 * i + 128, py = 256 * j + 128;
-  const long long w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
+  const double w0 = edge_fn(B, C, px, py), w1 = edge_fn(C, A, px, py), w2 = edge_fn(A, B, px, py);
   const bool covered = (area != 0) && (w0 > 0 || (w0 == 0 && owns_edge(B, C))) &&
                        (w1 > 0 || (w1 == 0 && owns_edge(C, A))) && (w2 > 0 || (w2 == 0 && owns_edge(A, B)));
   unsigned long long key = SUMA_EMPTY_KEY;
   if (covered) {
     const float fa = (float)area;
 #ifdef SUMA_BARY_PLAIN_DIV
-    float b0 = (float)w0 / fa, b1 = (float)w1 / fa, b2 = (float)w2 / fa;
+    float b0 = edge_to_float(w0) / fa, b1 = edge_to_float(w1) / fa, b2 = edge_to_float(w2) / fa;
 #else
     /* three quotients by one denominator; the operands are integers in [0, 2^46] over a positive integer area (X, Y
      * below 2^21, so every edge function is below 2^45 in magnitude), and a zero numerator gives an exact 0: the short
      * sequence of exact_div.h is correctly rounded there (tools/div_study.c) -- 18 instead of 33 instructions, the
      * same bits as the three `/` (the parity suite is the check) */
     const float fr = exdiv_refine(fa, __builtin_amdgcn_rcpf(fa));
-    float b0 = exdiv_quot((float)w0, fa, fr), b1 = exdiv_quot((float)w1, fa, fr), b2 = exdiv_quot((float)w2, fa, fr);
+    float b0 = exdiv_quot(edge_to_float(w0), fa, fr), b1 = exdiv_quot(edge_to_float(w1), fa, fr),
+          b2 = exdiv_quot(edge_to_float(w2), fa, fr);
 #endif
     float tu = (b0 * A.tu + b1 * B.tu) + b2 * C.tu;
     float tv = (b0 * A.tv + b1 * B.tv) + b2 * C.tv;
@@ -204,6 +216,7 @@ __device__ __forceinline__ uint32_t render_block_rank(bool flag, uint32_t* s_w, 
   return off + __popcll(ball & ((1ull << lane) - 1ull));
 }
 
+template <bool BIG> /* see the row / column split in phase 2 */
 __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_per_eu(5, 8))) k_render(RenderArgs a) {
   __shared__ float s_cand[RENDER_THREADS][9];   /* p.xyz, n.xyz, radius, pp.x, surfel id (bits) */
   __shared__ int32_t s_rec[RENDER_THREADS][17]; /* X0..3, Y0..3, z0..3 (float bits), i0, j0, w, surfel id; 17: a row stride of 16 words puts all lanes of a write on two banks */
@@ -462,7 +475,13 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
             const uint32_t excl = src ? s_incl[src - 1] : 0u;
             const int32_t* r = s_rec[src];
             const uint32_t q = t - excl, w = (uint32_t)r[14];
-            const uint32_t qj = q / w, qi = q - qj * w;
+            /* row / column of test q in a box w pixels wide.  An unsigned 32-bit division is ~25 instructions;
+             * floor(q / w) = floor((q + 0.5) / w), and that quotient lies at least 0.5 / w away from every integer, which a
+             * product with the hardware reciprocal (1 ulp; error of the product below 1.5 * 2^-23 of its value) cannot
+             * bridge while q < 2^21 -- so the truncated product IS the row.  q is below the pixel count of the model
+             * image; BIG (an image of 2 M pixels or more: none of the suites comes near) is the instantiation that divides. */
+            const uint32_t qj = BIG ? q / w : (uint32_t)(((float)q + 0.5f) * __builtin_amdgcn_rcpf((float)w));
+            const uint32_t qi = q - __umul24(qj, w); /* both below 2^24 */
             const int32_t pi = r[12] + (int32_t)qi, pj = r[13] + (int32_t)qj;
             rvtx vt[4];
 #pragma unroll
@@ -478,7 +497,7 @@ __global__ void __launch_bounds__(RENDER_THREADS) __attribute__((amdgpu_waves_pe
             const unsigned long long ka = raster_key(vt[0], vt[1], vt[2], pi, pj, id, slot.tie);
             const unsigned long long kb = raster_key(vt[2], vt[1], vt[3], pi, pj, id, slot.tie);
             key[u] = ka < kb ? ka : kb;
-            pix[u] = (uint32_t)pj * (uint32_t)a.q.W + (uint32_t)pi;
+            pix[u] = __umul24((uint32_t)pj, (uint32_t)a.q.W) + (uint32_t)pi; /* row, width < 2^24 */
             msk[u] = (uint32_t)r[16];
           }
         }
@@ -607,6 +626,13 @@ static void set_m4(m4& d, const float* s) {
   for (int i = 0; i < 16; ++i) d.m[i] = s[i];
 }
 
+/* the instantiation for this model image (see the row / column split in phase 2) */
+static void run_render(suma_ctx* c, const RenderArgs& a, uint32_t grid) {
+  if (c->Pm >= ((size_t)1 << 21))
+    k_render<true><<<grid, RENDER_THREADS, 0, c->ls>>>(a);
+  else
+    k_render<false><<<grid, RENDER_THREADS, 0, c->ls>>>(a);
+}
 static RenderArgs render_args(suma_ctx* c, float conf_threshold, int32_t thr) {
   RenderArgs a;
   a.surfels = c->surfels[c->cur];
@@ -678,7 +704,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     a.merged = (memcmp(inv_old, inv_new, sizeof(inv_old)) == 0 && !getenv("SUMA_RENDER_NO_MERGE")) ? 1 : 0;
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
+      run_render(c, a, stream_grid(c));
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -706,7 +732,7 @@ hipError_t launch_map_render(suma_ctx* c, const float* pose_old, const float* po
     set_m4(a.slot[0].inv_pose, inv_old);
     {
       ProfScope ps(c, "k4_render_surfels", 64.0 * S);
-      k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
+      run_render(c, a, stream_grid(c));
     }
     ResolveArgs r = resolve_args(c);
     set_m4(r.inv_a, inv_old);
@@ -747,7 +773,7 @@ hipError_t launch_map_render_single(suma_ctx* c, const float* pose, float conf_t
   a.k7_enabled = fuse_k7;
   {
     ProfScope ps(c, fuse_k7 ? "k4k7_render_indexmap" : "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
+    run_render(c, a, stream_grid(c));
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv);
@@ -792,7 +818,7 @@ hipError_t launch_map_render_composed(suma_ctx* c, const float* pose_old, const 
   set_m4(a.slot[1].inv_pose, inv_new);
   {
     ProfScope ps(c, "k4_render_surfels", 64.0 * (double)c->known_surfels);
-    k_render<<<stream_grid(c), RENDER_THREADS, 0, c->ls>>>(a);
+    run_render(c, a, stream_grid(c));
   }
   ResolveArgs r = resolve_args(c);
   set_m4(r.inv_a, inv_old);
