@@ -593,6 +593,25 @@ def test_pipeline_model_image_differs_from_data_image(hip, oracle_lib):
         frames_equal(hp.frame(2), op.frame(2), f"scan {k} model frame")
 
 
+def test_model_image_of_two_million_pixels(hip, oracle_lib):
+    """a model image of 2048 x 1024 = 2^21 pixels: k_render splits a pixel test's index into row and column with a
+    reciprocal while the index stays below 2^21 and with the integer division from there on (its BIG instantiation,
+    launch_map_render / run_render) -- the rendered frames, poses and map equal the oracle's either way"""
+    from semantic_suma_amd.types import default_params
+    p = default_params(data_width=900, data_height=64, model_width=2048, model_height=1024, model_fov_up=3.0,
+                       model_fov_down=-25.0)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p, threads=THREADS)
+    for k in range(3):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=6)
+        op.process_scan(pts, lab, prob, fixed_iterations=6)
+        assert np.array_equal(hp.getCurrentPose(), op.pose()), f"scan {k} pose"
+        assert hp.map.getAllSurfels().tobytes() == op.ctx.map_surfels().tobytes(), f"scan {k} surfels"
+        for w in (1, 2):
+            frames_equal(hp.frame(w), op.frame(w), f"scan {k} frame {w}")
+
+
 def test_tiny_and_odd_image_sizes(hip, oracle_lib):
     """16 beams x 180 columns, a width that is not a multiple of any tile size, and two images whose pixel count is
     not a multiple of the 64-lane wave (450 x 16 = 112.5 waves, 333 x 10): the wave reductions of K6 must not lose the
