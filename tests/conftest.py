@@ -14,6 +14,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+# Order of the suite under `-x`: per-kernel parity first, the long / multi-pipeline / whole-sequence cases last, so that
+# one late failure can never hide the per-kernel evidence again (round 5: a stopwatch assert in test_gpu_long.py stopped
+# the driver's run before test_gpu_parity.py had started).  Files not named here keep their alphabetical place between.
+_ORDER_FIRST = ["test_abi", "test_gpu_parity", "test_gpu_phases", "test_gpu_dist", "test_ref_golden", "test_golden",
+                "test_gpu_gl_golden", "test_gpu_cpp", "test_gpu_adapter"]
+_ORDER_LAST = ["test_gpu_long"]
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def key(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        if mod in _ORDER_FIRST:
+            return (0, _ORDER_FIRST.index(mod))
+        if mod in _ORDER_LAST:
+            return (2, _ORDER_LAST.index(mod))
+        return (1, 0)
+    items.sort(key=key)  # stable: the order inside a file is the file's
+
+
 @pytest.fixture(scope="session")
 def oracle_lib():
     """TEST INFRASTRUCTURE: the CPU restatement of the reference path (oracle/), built with gcc."""
