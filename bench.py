@@ -308,6 +308,7 @@ def main():
                     help="least number of scans of the host-vector entry's sample (it is max(--steps, this))")
     ap.add_argument("--no-host-vectors", action="store_true",
                     help="skip the host-vector entry (suma_pipeline_process_scan from pageable arrays) timed behind the contract's region")
+    ap.add_argument("--no-loop-closure", action="store_true", help="skip the loop-closure verification timing (batched vs serial)")
     ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11", "adapter"],
                     help="single: BASELINE configs[1] (the bench contract); hypotheses: configs[2], 8 ICP hypotheses per scan "
                          "sharded over the ranks; sequences11: configs[3], the 11 KITTI sequence lengths (scaled) LPT-assigned")
@@ -506,6 +507,42 @@ def main():
         run(n_before + K + HVW + HV, n_before + K + HVW + HV + E)
         kernels = ctx.profile_get()
     ctx.profile(0)
+    # ---- the device side of a loop-closure verification (SurfelMapping.cpp:679-757: render_inactive, three
+    #      initial guesses minimised + evaluated, render_composed + evaluation for a guess that passes) on the steady map,
+    #      batched (suma_loop_closure_verify: the guesses are ONE Gauss-Newton chain, grid.y = guess) against the reference's
+    #      one-by-one sequencing (suma_loop_closure_verify_serial) and against a single guess.  Untimed extra, rank 0.
+    loop_closure = None
+    if rank == 0 and world == 1 and not args.no_loop_closure:
+        try:
+            cur = pipe.frame(0)
+            prior = pipe.getCurrentPose().astype(np.float64)
+            Rz = np.eye(4)
+            Rz[:2, :2] = -Rz[:2, :2]
+            half = np.eye(4)
+            half[0, 3] = 0.5
+            inits = [np.eye(4), Rz, half]
+            ctv = float(p.confidence_threshold)
+            reps = 20
+
+            def clock(guesses, gates, serial):
+                core.loop_closure_verify(ctx, cur, prior, guesses, prior, ctv, *gates, serial=serial)  # warm
+                ctx.synchronize()
+                t = time.perf_counter()
+                for _ in range(reps):
+                    r = core.loop_closure_verify(ctx, cur, prior, guesses, prior, ctv, *gates, serial=serial)
+                ctx.synchronize()
+                return 1e6 * (time.perf_counter() - t) / reps, [bool(x["passed"]) for x in r]
+
+            loop_closure = {"n_init": 3, "repetitions": reps, "map_surfels": pipe.map.size(), "unit": "us per verification"}
+            for name, gates in (("reference_gates", (0.2, 0.85)), ("no_guess_passes", (2.0, 0.85))):
+                b, pb = clock(inits, gates, False)
+                sq, ps = clock(inits, gates, True)
+                one, _ = clock(inits[:1], gates, False)
+                assert pb == ps
+                loop_closure[name] = {"batched": round(b, 1), "serial": round(sq, 1), "one_guess": round(one, 1),
+                                      "batched_over_one_guess": round(b / one, 3), "passed": pb}
+        except Exception as e:  # noqa: BLE001 -- an extra must never cost the bench line
+            print(f"loop_closure leg not taken: {e!r}", file=sys.stderr)
     if seq is None:  # synthetic trajectory: known ground truth
         gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + n_before + K - 1)  # pose taken before the host-vector stretch
         drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
@@ -542,6 +579,8 @@ def main():
         out["cold_start"] = cold_start  # the first K scans of the sequence (growing map): NOT the headline
     if host_vectors is not None:
         out["host_vector_entry"] = host_vectors
+    if loop_closure is not None:
+        out["loop_closure_verify"] = loop_closure
 
     def derive(ks):
         for k in ks:

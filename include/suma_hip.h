@@ -126,7 +126,8 @@ int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], doub
  * SurfelMapping.cpp:391).  *n_hist = entries the minimisation pushed; min(that, history_cap) x 16 doubles are copied. */
 int suma_icp_history(suma_ctx* ctx, double* history, uint32_t history_cap, uint32_t* n_hist);
 /* The history lives in ONE device buffer per context; every minimisation that records one (suma_icp_minimize, also inside
- * suma_loop_closure_verify / _track) overwrites it and advances this counter.  The reference keeps history_ per optimizer
+ * suma_loop_closure_verify_serial / suma_loop_closure_track; NOT the batched suma_loop_closure_verify nor the scan
+ * pipeline's own minimisations, which record none) overwrites it and advances this counter.  The reference keeps history_ per optimizer
  * object (LieGaussNewton.h:72): an adapter object notes the counter after ITS minimisation and refuses to hand out
  * another chain's poses when it has moved (include/suma_adapter.hpp, LieGaussNewton::history). */
 uint64_t suma_icp_history_sequence(const suma_ctx* ctx);
@@ -281,6 +282,16 @@ int suma_loop_closure_verify(suma_ctx* ctx, const suma_frame* current, const dou
                              const double* initializations, uint32_t n_init, const float pose_new[16],
                              float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
                              suma_loop_result* out);
+/* suma_loop_closure_verify minimises the initial guesses as ONE batched Gauss-Newton chain (grid.y = guess) with the
+ * per-guess evaluation (:705) riding on the same chain states: one chain of launches and one synchronisation when no
+ * guess (or only the last) passes; after a guess that passes, the later guesses -- which the reference minimises
+ * against composedFrame() (:718-719) -- are redone as a batch against that frame.  This entry is the reference's
+ * sequencing literally (one minimisation, one evaluation, two host round trips per guess): identical results, kept as
+ * the cross-check of the batched form and for the A/B timing in bench.py. */
+int suma_loop_closure_verify_serial(suma_ctx* ctx, const suma_frame* current, const double pose_prior[16],
+                                    const double* initializations, uint32_t n_init, const float pose_new[16],
+                                    float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
+                                    suma_loop_result* out);
 
 /* the same on a pipeline's own state between suma_pipeline_update_pose and suma_pipeline_update_map: current frame,
  * currentPose_new_ and getConfidenceThreshold() are the pipeline's (SurfelMapping.cpp:679-719) */

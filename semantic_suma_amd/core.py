@@ -156,6 +156,7 @@ def lib():
     L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.suma_map_download_cached_tile.argtypes = [vp, C.c_int32, C.c_int32, vp, u32, C.POINTER(u32)]
     L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
+    L.suma_loop_closure_verify_serial.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
     L.suma_pipeline_destroy.argtypes = [vp]
     L.suma_pipeline_destroy.restype = None
@@ -663,22 +664,18 @@ class SurfelMap:
 
 
 def loop_closure_verify(ctx: Context, current: Frame, pose_prior, initializations, pose_new, conf_threshold: float,
-                        min_valid_ratio: float = 0.2, max_outlier_ratio: float = 0.85):
-    """device side of SurfelMapping::checkLoopClosure (SurfelMapping.cpp:662-757); returns one dict per guess"""
+                        min_valid_ratio: float = 0.2, max_outlier_ratio: float = 0.85, serial: bool = False):
+    """device side of SurfelMapping::checkLoopClosure (SurfelMapping.cpp:662-757); returns one dict per guess.
+    The guesses run as one batched Gauss-Newton chain; serial=True is the reference's one-by-one sequencing (same bits)."""
     prior = _cm(pose_prior, np.float64)
     inits = np.ascontiguousarray(np.asarray(initializations, dtype=np.float64).reshape(-1, 4, 4).transpose(0, 2, 1))
     pn = _cm(pose_new, np.float32)
     n = inits.shape[0]
     res = (LoopResult * n)()
-    ctx.check(ctx.L.suma_loop_closure_verify(ctx.h, current.h, _ptr(prior), _ptr(inits), n, _ptr(pn), conf_threshold,
-                                             min_valid_ratio, max_outlier_ratio, res), "suma_loop_closure_verify")
-    out = []
-    for k in range(n):
-        r = res[k]
-        out.append(dict(gn_pose=np.array(r.gn_pose[:]).reshape(4, 4).T.copy(), after_minimize=r.after_minimize.as_dict(),
-                        passed=bool(r.passed), pose_old=np.array(r.pose_old[:], dtype=np.float32).reshape(4, 4).T.copy(),
-                        composed=r.composed.as_dict(), JtJ=np.array(r.JtJ[:]).reshape(6, 6).T.copy()))
-    return out
+    fn = ctx.L.suma_loop_closure_verify_serial if serial else ctx.L.suma_loop_closure_verify
+    ctx.check(fn(ctx.h, current.h, _ptr(prior), _ptr(inits), n, _ptr(pn), conf_threshold, min_valid_ratio,
+                 max_outlier_ratio, res), "suma_loop_closure_verify")
+    return _loop_results(res, n)
 
 
 def _loop_results(res, n):

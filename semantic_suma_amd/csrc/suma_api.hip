@@ -1417,7 +1417,88 @@ static void mul4_dd(const double* A, const double* B, double* C) {
           ((A[r] * B[4 * c] + A[4 + r] * B[4 * c + 1]) + A[8 + r] * B[4 * c + 2]) + A[12 + r] * B[4 * c + 3];
 }
 
+/* One speculative round of the verification: the chains of `n` initial guesses as ONE batched minimisation (grid.y =
+ * guess) against whatever model frame the objective points at, then -- still without a host round trip -- the
+ * jacobianProducts evaluation at the pose each chain ended on (SurfelMapping.cpp:705), as one more batched pixel pass
+ * with eval_only set on the SAME chain states (the state's Frame2Model::iteration_ has kept running, exactly the value
+ * the sequential form passes in) and its consume launch.  One copy + one synchronisation for all guesses. */
+static int verify_round(suma_ctx* c, const double* inits, uint32_t n) {
+  int r = enqueue_minimize(c, inits, n, 0); /* :700, n chains side by side */
+  if (r) return r;
+  const uint32_t iter_arg = c->p.max_iterations > 0 ? c->p.max_iterations : 0xffffffffu;
+  {
+    ProfScope ps(c, "k6_icp_step", 96.0 * (double)c->icp_current->width * c->icp_current->height * n);
+    CK(launch_icp_iteration(c, n, iter_arg, (double)c->p.stopping_threshold, (double)c->p.delta, 1, 0, 1)); /* :705 */
+  }
+  {
+    ProfScope ps(c, "k6_icp_finish", 0.0);
+    CK(launch_icp_iteration(c, n, iter_arg, (double)c->p.stopping_threshold, (double)c->p.delta, 1, 0, 0));
+  }
+  CK(hipMemcpyAsync(c->h_gn, gn_result(c), (size_t)n * sizeof(GnState), hipMemcpyDeviceToHost, c->stream));
+  CK(hipStreamSynchronize(c->stream));
+  host_synced(c);
+  return SUMA_OK;
+}
+
+/* SurfelMapping.cpp:679-757 with the initial guesses BATCHED.  The reference minimises the guesses
+ * one after the other against oldMapFrame(); its quirk: the first guess that passes the gates re-points the objective at
+ * composedFrame() (:718-719) and every LATER guess is minimised against that frame.  So the batch is speculative: all
+ * remaining guesses run side by side against the current model; the host walks the results in order and, at the first
+ * one that passes, renders the composed view, evaluates it (:720-723) and throws the later speculative results away --
+ * they are redone, again as one batch, against the composed frame.  No guess passes (the common case: a candidate is
+ * rejected) or only the last one does: ONE chain of launches and one synchronisation for the whole verification, where
+ * the sequential form pays n_init chains and 2 n_init host round trips.  Results are the sequential form's bit for bit
+ * (suma_loop_closure_verify_serial, kept for the cross-check and the A/B timing). */
 extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, const double pose_prior[16],
+                                        const double* initializations, uint32_t n_init, const float pose_new[16],
+                                        float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
+                                        suma_loop_result* out) {
+  if (!c || !current || !pose_prior || !initializations || !pose_new || !out) return SUMA_ERR_INVALID;
+  float prior_f[16];
+  for (int i = 0; i < 16; ++i) prior_f[i] = (float)pose_prior[i];
+  int r = suma_map_render_inactive(c, prior_f, conf_threshold); /* :679 */
+  if (r) return r;
+  r = suma_icp_set_data(c, current, c->old_frame); /* :693 */
+  if (r) return r;
+  uint32_t start = 0;
+  while (start < n_init) {
+    const uint32_t n = (n_init - start) < SUMA_MAX_HYP ? (n_init - start) : SUMA_MAX_HYP;
+    r = verify_round(c, initializations + 16 * (size_t)start, n);
+    if (r) return r;
+    uint32_t next = start + n;
+    for (uint32_t k = start; k < start + n; ++k) {
+      const GnState& g = c->h_gn[k - start];
+      suma_loop_result* o = &out[k];
+      memset(o, 0, sizeof(*o));
+      memcpy(o->gn_pose, g.Tk, sizeof(g.Tk));
+      fill_stats(g, &o->after_minimize);
+      const suma_icp_stats& s0 = o->after_minimize;
+      const float valid_ratio = (float)s0.valid / (float)(s0.valid + s0.invalid);
+      const float outlier_ratio = (float)s0.outlier / (float)(s0.outlier + s0.inlier);
+      double pd[16];
+      mul4_dd(pose_prior, o->gn_pose, pd);
+      for (int i = 0; i < 16; ++i) o->pose_old[i] = (float)pd[i];
+      o->passed = (valid_ratio > min_valid_ratio && outlier_ratio < max_outlier_ratio) ? 1 : 0; /* :713 */
+      if (o->passed) {
+        r = suma_map_render_composed(c, o->pose_old, pose_new, conf_threshold); /* :717 */
+        if (r) return r;
+        r = suma_icp_set_data(c, current, c->composed_frame); /* :719 -- the model of every later guess */
+        if (r) return r;
+        double I[16];
+        for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.0 : 0.0;
+        r = suma_icp_jacobian_products(c, I, 0, o->JtJ, nullptr, nullptr, &o->composed); /* :720-723; overwrites h_gn[0] */
+        if (r) return r;
+        next = k + 1; /* what was speculated behind this guess saw the wrong model: redo it */
+        break;
+      }
+    }
+    start = next;
+  }
+  return SUMA_OK;
+}
+
+/* the reference's sequencing literally: one minimisation, one evaluation and two host round trips per guess */
+extern "C" int suma_loop_closure_verify_serial(suma_ctx* c, const suma_frame* current, const double pose_prior[16],
                                         const double* initializations, uint32_t n_init, const float pose_new[16],
                                         float conf_threshold, float min_valid_ratio, float max_outlier_ratio,
                                         suma_loop_result* out) {
