@@ -156,7 +156,8 @@ class Frame2Model {
     last_ = last;
     iteration_ = 0;
   }
-  void initialize(const double* pose16) { std::memcpy(pose_, pose16, sizeof(pose_)); iteration_ = 0; }
+  /* Objective::initialize (Objective.h:58) sets the pose and nothing else: iteration_ is reset by setData only */
+  void initialize(const double* pose16) { std::memcpy(pose_, pose16, sizeof(pose_)); }
   /* Objective::residual is "not implemented" in the reference too (Frame2Model.cpp:131-134) */
   double residual(const double* /*delta6*/) { throw std::runtime_error("not implemented."); }
   /* returns F; JtJ 6x6 column-major, Jtf 6 (Eigen::MatrixXd::data() of the reference's arguments) */
@@ -210,6 +211,8 @@ class LieGaussNewton {
   explicit LieGaussNewton(Context& ctx) : ctx_(ctx) { std::memset(&stats_, 0, sizeof(stats_)); }
   int32_t minimize(Frame2Model& F, const double* T0) {
     F.bind();
+    /* Frame2Model::iteration_ runs on across minimisations on one setData (SurfelMapping.cpp:693-700) */
+    check(ctx_.get(), suma_icp_set_iteration(ctx_.get(), F.iteration_), "Frame2Model::iteration_");
     /* the pose history stays on the device until history() is called (the reference's caller only draws it,
      * SurfelMapping.cpp:391): the minimisation costs the host one poll of a pinned record, no copy */
     check(ctx_.get(), suma_icp_minimize(ctx_.get(), T0, pose_, nullptr, 0, &n_hist_, &stats_), "LieGaussNewton::minimize");
@@ -217,7 +220,7 @@ class LieGaussNewton {
     history_seq_ = suma_icp_history_sequence(ctx_.get());
     std::memcpy(F.pose_, pose_, sizeof(pose_));
     F.stats_ = stats_;
-    F.iteration_ = stats_.iterations;
+    F.iteration_ += stats_.iterations + (stats_.converged ? 1u : 0u); /* one Objective::increment per step, Objective.h:45-48 */
     check(ctx_.get(), suma_icp_information(ctx_.get(), information_), "LieGaussNewton::information");
     return 0; /* the reference returns 0 from every path of minimize (LieGaussNewton.cpp:37) */
   }

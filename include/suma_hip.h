@@ -121,6 +121,12 @@ int suma_icp_jacobian_products(suma_ctx* ctx, const double pose[16], uint32_t it
  *      history (optional): history_cap x 16 doubles receive LieGaussNewton::history(); *n_hist = entries pushed. */
 int suma_icp_minimize(suma_ctx* ctx, const double T0[16], double T_out[16], double* history, uint32_t history_cap,
                       uint32_t* n_hist, suma_icp_stats* stats);
+/* Frame2Model::iteration_ the NEXT suma_icp_minimize starts with (one shot; suma_icp_set_data resets it to 0 like
+ * Frame2Model::setData, Frame2Model.cpp:117-123).  The reference resets the counter in setData ONLY: a caller that
+ * minimises several times on one setData -- the loop over the initial guesses in checkLoopClosure,
+ * SurfelMapping.cpp:693-700 -- starts its later minimisations with iteration_ > 0, which the Tukey weight reads
+ * (Frame2Model_jacobians.geom:129).  An adapter object passes its own counter here before every minimisation. */
+int suma_icp_set_iteration(suma_ctx* ctx, uint32_t iteration);
 /* LieGaussNewton::history() (LieGaussNewton.h:44) of the last suma_icp_minimize, fetched on demand: the device always
  * records it, the copy is only paid by callers that look at it (the reference's caller keeps it for drawing,
  * SurfelMapping.cpp:391).  *n_hist = entries the minimisation pushed; min(that, history_cap) x 16 doubles are copied. */

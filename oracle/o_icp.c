@@ -240,16 +240,22 @@ void ora_se3_exp(const double x[6], double T[16]) {
   }
 }
 
-/* LieGaussNewton::minimize / step.  history receives every Tk pushed at LieGaussNewton.cpp:24. */
-void ora_icp_minimize(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
-                      double T_out[16], double* history, uint32_t history_cap, uint32_t* n_hist,
-                      suma_icp_stats* st) {
+/* LieGaussNewton::minimize / step.  history receives every Tk pushed at LieGaussNewton.cpp:24.
+ * iteration0 = Frame2Model::iteration_ when the minimisation starts.  ONLY Frame2Model::setData resets that counter
+ * (Frame2Model.cpp:117-123); LieGaussNewton::initialize -> Objective::initialize (LieGaussNewton.cpp:36-51,
+ * Objective.h:58) sets the pose and nothing else, and every Objective::increment advances it (Objective.h:45-48).  A
+ * caller that minimises twice on one setData -- the loop over the initial guesses of checkLoopClosure,
+ * SurfelMapping.cpp:693-700 -- therefore starts its later minimisations with iteration_ > 0, which the Tukey weight
+ * reads (Frame2Model_jacobians.geom:129: `iteration > 0`). */
+void ora_icp_minimize_from(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
+                           uint32_t iteration0, double T_out[16], double* history, uint32_t history_cap,
+                           uint32_t* n_hist, suma_icp_stats* st) {
   const uint32_t max_iter = c->p.max_iterations;
   const double epsilon = (double)c->p.stopping_threshold, delta = (double)c->p.delta;
   double Tk[16];
   memcpy(Tk, T0, sizeof(Tk));
   double last_error = (double)3.402823466e+38f; /* std::numeric_limits<float>::max(), :48 */
-  uint32_t iteration = 0;                         /* Frame2Model::setData resets it, Frame2Model.cpp:122 */
+  uint32_t iteration = iteration0;
   uint32_t k = 0, nh = 0, converged = 0;
   suma_icp_stats s;
   memset(&s, 0, sizeof(s));
@@ -288,4 +294,12 @@ void ora_icp_minimize(ora_ctx* c, const ora_frame* current, const ora_frame* mod
     st->iterations = k;
     st->converged = converged;
   }
+}
+
+/* the minimisation right behind a setData (iteration_ = 0): every call site of the scan path (SurfelMapping.cpp:384-388,
+ * 443-445, 553-554) */
+void ora_icp_minimize(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
+                      double T_out[16], double* history, uint32_t history_cap, uint32_t* n_hist,
+                      suma_icp_stats* st) {
+  ora_icp_minimize_from(c, current, model, T0, 0u, T_out, history, history_cap, n_hist, st);
 }

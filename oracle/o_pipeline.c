@@ -289,12 +289,15 @@ void ora_loop_closure_verify(ora_ctx* c, const ora_frame* current, const double 
   o_cast(pose_prior, prior_f);
   ora_map_render_inactive(c, prior_f, conf_threshold); /* :679 */
   const ora_frame* model = ora_map_frame(c, SUMA_FRAME_OLD); /* :693 */
+  /* Frame2Model::iteration_: reset by the setData calls at :693 and :719 only, advanced by every increment -- it keeps
+   * counting ACROSS the guesses (the Tukey weight of a later guess is on from its first step) */
+  uint32_t iteration = 0;
   for (uint32_t k = 0; k < n_init; ++k) {
     ora_loop_result* o = &out[k];
     memset(o, 0, sizeof(*o));
     suma_icp_stats mst;
-    ora_icp_minimize(c, current, model, inits + 16 * (size_t)k, o->gn_pose, NULL, 0, NULL, &mst); /* :700 */
-    const uint32_t iteration = mst.iterations + (mst.converged ? 1u : 0u); /* Frame2Model::iteration_ keeps counting */
+    ora_icp_minimize_from(c, current, model, inits + 16 * (size_t)k, iteration, o->gn_pose, NULL, 0, NULL, &mst); /* :700 */
+    iteration += mst.iterations + (mst.converged ? 1u : 0u); /* one increment per step, also the converged one */
     ora_icp_jacobian_products(c, current, model, o->gn_pose, iteration, NULL, NULL, NULL, &o->after_minimize); /* :705 */
     o->after_minimize.iterations = mst.iterations;
     o->after_minimize.converged = mst.converged;
@@ -308,6 +311,7 @@ void ora_loop_closure_verify(ora_ctx* c, const ora_frame* current, const double 
     if (o->passed) {
       ora_map_render_composed(c, o->pose_old, pose_new, conf_threshold); /* :717 */
       model = ora_map_frame(c, SUMA_FRAME_COMPOSED);                     /* :719 */
+      iteration = 0;                                                      /* setData, Frame2Model.cpp:122 */
       double I[16];
       o_eye(I);
       ora_icp_jacobian_products(c, current, model, I, 0, NULL, o->JtJ, NULL, &o->composed); /* :720-723 */

@@ -79,6 +79,7 @@ def lib(variant: str = ""):
     L.ora_icp_jacobian_products.restype = C.c_double
     L.ora_icp_jacobian_products.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, vp, C.POINTER(IcpStats)]
     L.ora_icp_minimize.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(IcpStats)]
+    L.ora_icp_minimize_from.argtypes = [vp, vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(IcpStats)]
     L.ora_map_reset.argtypes = [vp]
     L.ora_map_update.argtypes = [vp, vp, vp]
     L.ora_map_render.argtypes = [vp, vp, vp, C.c_float, vp]
@@ -238,14 +239,15 @@ class Oracle:
         return F, acc, JtJ, Jtr, st
 
     # -- LieGaussNewton::minimize
-    def minimize(self, current, model, T0, history_cap=64):
+    def minimize(self, current, model, T0, history_cap=64, iteration0=0):
+        """iteration0: Frame2Model::iteration_ at the start (0 right behind a setData, Frame2Model.cpp:117-123)"""
         T0 = np.ascontiguousarray(np.asarray(T0, dtype=np.float64).T)
         T = np.zeros((4, 4), dtype=np.float64)
         hist = np.zeros((history_cap, 4, 4), dtype=np.float64)
         nh = C.c_uint32(0)
         st = IcpStats()
-        self.L.ora_icp_minimize(self.h, current.h, model.h, _ptr(T0), _ptr(T), _ptr(hist), history_cap, C.byref(nh),
-                                C.byref(st))
+        self.L.ora_icp_minimize_from(self.h, current.h, model.h, _ptr(T0), iteration0, _ptr(T), _ptr(hist), history_cap,
+                                     C.byref(nh), C.byref(st))
         n = min(nh.value, history_cap)
         return T.T.copy(), hist[:n].transpose(0, 2, 1).copy(), st
 

@@ -55,6 +55,11 @@ double ora_icp_jacobian_products(ora_ctx* c, const ora_frame* current, const ora
 /* LieGaussNewton::minimize (src/core/LieGaussNewton.cpp:13-79): history gets (n_hist) 4x4 doubles */
 void ora_icp_minimize(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
                       double T_out[16], double* history, uint32_t history_cap, uint32_t* n_hist, suma_icp_stats* st);
+/* the same with Frame2Model::iteration_ starting at iteration0 (a minimisation that is NOT the first one behind a
+ * setData: SurfelMapping.cpp:693-700) */
+void ora_icp_minimize_from(ora_ctx* c, const ora_frame* current, const ora_frame* model, const double T0[16],
+                           uint32_t iteration0, double T_out[16], double* history, uint32_t history_cap,
+                           uint32_t* n_hist, suma_icp_stats* st);
 
 /* SurfelMap (src/core/SurfelMap.cpp) */
 void ora_map_reset(ora_ctx* c);

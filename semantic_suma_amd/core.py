@@ -155,6 +155,7 @@ def lib():
     L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
     L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.suma_map_download_cached_tile.argtypes = [vp, C.c_int32, C.c_int32, vp, u32, C.POINTER(u32)]
+    L.suma_icp_set_iteration.argtypes = [vp, u32]
     L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_loop_closure_verify_serial.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
@@ -416,8 +417,8 @@ class Frame2Model:
         c.check(c.L.suma_icp_set_objective(c.h, C.byref(self.objective)), "suma_icp_set_objective")
 
     def initialize(self, pose):
+        """Objective::initialize (Objective.h:58): the pose and nothing else -- iteration_ is reset by setData only"""
         self._pose = np.asarray(pose, dtype=np.float64).copy()
-        self._iteration = 0
 
     def pose(self):
         return self._pose
@@ -469,11 +470,14 @@ class LieGaussNewton:
         nh = C.c_uint32(0)
         c = self.ctx
         objective._bind()
+        # Frame2Model::iteration_ runs on across minimisations on one setData (SurfelMapping.cpp:693-700)
+        c.check(c.L.suma_icp_set_iteration(c.h, objective._iteration), "suma_icp_set_iteration")
         # the pose history stays on the device until history() asks for it (suma_icp_history)
         c.check(c.L.suma_icp_minimize(c.h, _ptr(T0), _ptr(T), None, 0, C.byref(nh), C.byref(self.stats)), "suma_icp_minimize")
         self._pose = T.T.copy()
         objective._pose = self._pose
         objective.stats = self.stats
+        objective._iteration += self.stats.iterations + (1 if self.stats.converged else 0)  # one increment per step
         self._history, self._history_cap = None, history_cap
         self._history_seq = c.L.suma_icp_history_sequence(c.h)
         return 0

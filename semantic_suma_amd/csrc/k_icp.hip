@@ -335,14 +335,14 @@ __device__ __forceinline__ void gn_reset(GnState* g, int t, uint32_t iteration0)
 }
 
 /* LieGaussNewton::initialize (LieGaussNewton.cpp:36-51): one block per hypothesis */
-__global__ void k_gn_init(GnState* gn, const double* T0s, double* history, uint32_t iteration0) {
+__global__ void k_gn_init(GnState* gn, const double* T0s, double* history, uint32_t iteration0, uint32_t iteration0_rest) {
   GnState* g = gn + blockIdx.x;
   int t = threadIdx.x;
   if (t < 16) {
     g->Tk[t] = T0s[16 * blockIdx.x + t];
     if (history != nullptr && blockIdx.x == 0) history[t] = T0s[t];
   }
-  gn_reset(g, t, iteration0);
+  gn_reset(g, t, blockIdx.x == 0 ? iteration0 : iteration0_rest);
 }
 #define ICP_RECORDS 8 /* accumulator records per hypothesis (power of two) */
 struct IterArgs {
@@ -956,7 +956,10 @@ static long long* part_buf(suma_ctx* c, uint32_t launch) {
   return (long long*)c->gn_partial + (size_t)(launch % 3u) * SUMA_MAX_HYP * ICP_RECORDS * SUMA_ACC_WORDS;
 }
 
-hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0) {
+/* iteration0 / iteration0_rest: Frame2Model::iteration_ the first / every other chain of the batch starts with (0 right
+ * behind a setData; > 0 for a minimisation that follows another one on the same setData, SurfelMapping.cpp:693-700) */
+hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0,
+                          uint32_t iteration0_rest) {
   double* hist = with_history ? c->gn_history : nullptr;
   c->gn_launch = 0;
   c->gn_init_pending = 0;
@@ -968,7 +971,7 @@ hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int 
   } else {
     hipError_t e = hipMemcpyAsync(c->gn_T0s, h_T0s, (size_t)n_hyp * 16 * sizeof(double), hipMemcpyHostToDevice, c->ls);
     if (e != hipSuccess) return e;
-    k_gn_init<<<n_hyp, 64, 0, c->ls>>>(gn_buf(c, 0), c->gn_T0s, hist, iteration0);
+    k_gn_init<<<n_hyp, 64, 0, c->ls>>>(gn_buf(c, 0), c->gn_T0s, hist, iteration0, iteration0_rest);
   }
   return hipGetLastError();
 }

@@ -672,6 +672,7 @@ extern "C" int suma_icp_set_data(suma_ctx* c, const suma_frame* current, const s
   if (!c || !current || !model) return SUMA_ERR_INVALID;
   c->icp_current = current;
   c->icp_model = model;
+  c->icp_iteration0 = 0; /* iteration_ = 0, Frame2Model.cpp:122 */
   return SUMA_OK;
 }
 
@@ -799,14 +800,15 @@ extern "C" int suma_icp_jacobian_products(suma_ctx* c, const double pose[16], ui
  * converged after SUMA_GN_HARD_CAP iterations is reported as an error instead of returned silently. */
 #define SUMA_GN_CHUNK 32u
 #define SUMA_GN_HARD_CAP (1u << 16)
-static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history) {
+static int enqueue_minimize(suma_ctx* c, const double* T0s, uint32_t n_hyp, int with_history, uint32_t iteration0 = 0,
+                            uint32_t iteration0_rest = 0) {
   const uint32_t max_iter = c->p.max_iterations;
   const uint32_t iter_arg = max_iter > 0 ? max_iter : 0xffffffffu;
   if (c->gate_pending) CK(flush_gate(c)); /* the chain reads the frame the side stream preprocessed (k_sync.hip) */
   accessed(c, c->icp_current);
   accessed(c, c->icp_model);
   if (with_history) c->hist_seq += 1; /* this chain overwrites the device-side pose history */
-  CK(launch_gn_init(c, T0s, n_hyp, with_history, 0));
+  CK(launch_gn_init(c, T0s, n_hyp, with_history, iteration0, iteration0_rest));
   /* launch j runs the pixel phase of iteration j after consuming the sums of iteration j-1; the
    * closing launch only consumes */
   const double launch_bytes = 96.0 * (double)c->icp_current->width * c->icp_current->height * n_hyp;
@@ -854,7 +856,9 @@ extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[
   c->gn_host_out = rec;
   c->gn_host_seq = c->rec_seq;
   c->gn_host_full = 1;
-  int r = enqueue_minimize(c, T0, 1, 1);
+  const uint32_t iteration0 = c->icp_iteration0; /* suma_icp_set_iteration, one shot */
+  c->icp_iteration0 = 0;
+  int r = enqueue_minimize(c, T0, 1, 1, iteration0);
   c->gn_host_out = nullptr;
   c->gn_host_full = 0;
   if (r) return r;
@@ -869,6 +873,12 @@ extern "C" int suma_icp_minimize(suma_ctx* c, const double T0[16], double T_out[
   c->last_n_hist = rec->n_hist;
   if (n_hist) *n_hist = rec->n_hist;
   if (history != nullptr && history_cap > 0) return suma_icp_history(c, history, history_cap, nullptr);
+  return SUMA_OK;
+}
+
+extern "C" int suma_icp_set_iteration(suma_ctx* c, uint32_t iteration) {
+  if (!c) return SUMA_ERR_INVALID;
+  c->icp_iteration0 = iteration;
   return SUMA_OK;
 }
 
@@ -1422,8 +1432,12 @@ static void mul4_dd(const double* A, const double* B, double* C) {
  * jacobianProducts evaluation at the pose each chain ended on (SurfelMapping.cpp:705), as one more batched pixel pass
  * with eval_only set on the SAME chain states (the state's Frame2Model::iteration_ has kept running, exactly the value
  * the sequential form passes in) and its consume launch.  One copy + one synchronisation for all guesses. */
-static int verify_round(suma_ctx* c, const double* inits, uint32_t n) {
-  int r = enqueue_minimize(c, inits, n, 0); /* :700, n chains side by side */
+static int verify_round(suma_ctx* c, const double* inits, uint32_t n, uint32_t iteration0) {
+  /* Frame2Model::iteration_ is reset by setData only (Frame2Model.cpp:117-123) and counts on across the guesses
+   * (SurfelMapping.cpp:693-700): the first guess of a round starts where the caller says, every later one behind at
+   * least one increment of its predecessor.  The shader reads the counter as `iteration > 0` and nothing else
+   * (Frame2Model_jacobians.geom:129, the Tukey weight), so "1" stands for the count a speculative chain cannot know. */
+  int r = enqueue_minimize(c, inits, n, 0, iteration0, iteration0 > 0 ? iteration0 : 1u); /* :700, n chains side by side */
   if (r) return r;
   const uint32_t iter_arg = c->p.max_iterations > 0 ? c->p.max_iterations : 0xffffffffu;
   {
@@ -1461,10 +1475,12 @@ extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, 
   r = suma_icp_set_data(c, current, c->old_frame); /* :693 */
   if (r) return r;
   uint32_t start = 0;
+  uint32_t iteration0 = 0; /* Frame2Model::iteration_ in front of guess `start`: 0 behind a setData (:693, :719) */
   while (start < n_init) {
     const uint32_t n = (n_init - start) < SUMA_MAX_HYP ? (n_init - start) : SUMA_MAX_HYP;
-    r = verify_round(c, initializations + 16 * (size_t)start, n);
+    r = verify_round(c, initializations + 16 * (size_t)start, n, iteration0);
     if (r) return r;
+    iteration0 = 1; /* a round that ends without a pass (more guesses than SUMA_MAX_HYP): the counter has moved */
     uint32_t next = start + n;
     for (uint32_t k = start; k < start + n; ++k) {
       const GnState& g = c->h_gn[k - start];
@@ -1489,6 +1505,7 @@ extern "C" int suma_loop_closure_verify(suma_ctx* c, const suma_frame* current, 
         r = suma_icp_jacobian_products(c, I, 0, o->JtJ, nullptr, nullptr, &o->composed); /* :720-723; overwrites h_gn[0] */
         if (r) return r;
         next = k + 1; /* what was speculated behind this guess saw the wrong model: redo it */
+        iteration0 = 0; /* setData at :719; the evaluation at identity increments nothing */
         break;
       }
     }
@@ -1509,15 +1526,17 @@ extern "C" int suma_loop_closure_verify_serial(suma_ctx* c, const suma_frame* cu
   if (r) return r;
   r = suma_icp_set_data(c, current, c->old_frame); /* :693 */
   if (r) return r;
+  uint32_t iteration = 0; /* Frame2Model::iteration_: reset by setData (:693, :719) only, it counts on across the guesses */
   for (uint32_t k = 0; k < n_init; ++k) {
     suma_loop_result* o = &out[k];
     memset(o, 0, sizeof(*o));
     suma_icp_stats mst;
+    c->icp_iteration0 = iteration;
     r = suma_icp_minimize(c, initializations + 16 * (size_t)k, o->gn_pose, nullptr, 0, nullptr, &mst); /* :700 */
     if (r) return r;
-    /* objective_->jacobianProducts(JtJ, Jtr) at the pose the minimisation left (:705); Frame2Model's
-     * iteration counter keeps running, which only matters for the Tukey weight */
-    const uint32_t iteration = mst.iterations + (mst.converged ? 1u : 0u);
+    /* objective_->jacobianProducts(JtJ, Jtr) at the pose the minimisation left (:705); one increment per step, also
+     * the converged one (Objective.h:45-48) -- the counter only matters for the Tukey weight */
+    iteration += mst.iterations + (mst.converged ? 1u : 0u);
     r = suma_icp_jacobian_products(c, o->gn_pose, iteration, nullptr, nullptr, nullptr, &o->after_minimize);
     if (r) return r;
     o->after_minimize.iterations = mst.iterations;
@@ -1538,6 +1557,7 @@ extern "C" int suma_loop_closure_verify_serial(suma_ctx* c, const suma_frame* cu
       for (int i = 0; i < 16; ++i) I[i] = (i % 5 == 0) ? 1.0 : 0.0;
       r = suma_icp_jacobian_products(c, I, 0, o->JtJ, nullptr, nullptr, &o->composed); /* :720-723 */
       if (r) return r;
+      iteration = 0; /* setData at :719 */
     }
   }
   return SUMA_OK;

@@ -175,6 +175,7 @@ struct suma_ctx {
   float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
   int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
   uint32_t gn_iteration0;
+  uint32_t icp_iteration0; /* suma_icp_set_iteration: Frame2Model::iteration_ for the NEXT suma_icp_minimize (one shot) */
   double gn_T0_host[16];
   double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
   double* gn_T0s;      /* SUMA_MAX_HYP x 16 staging for batched starts */
@@ -344,7 +345,8 @@ hipError_t launch_preprocess(suma_ctx* c, const float4* d_pts, const float* d_la
 hipError_t launch_k1_average(suma_ctx* c, const float4* d_pts, const float* d_labels, const float* d_probs, uint32_t n,
                              uint32_t timestamp, float4* vertex, float4* raw_semantic);
 hipError_t launch_k1c_bilateral(suma_ctx* c, float4* vertex);
-hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0);
+hipError_t launch_gn_init(suma_ctx* c, const double* h_T0s, uint32_t n_hyp, int with_history, uint32_t iteration0,
+                          uint32_t iteration0_rest = 0);
 hipError_t launch_icp_iteration(suma_ctx* c, uint32_t n_hyp, uint32_t max_iter, double epsilon, double delta,
                                 int eval_only, int with_history, int pixel);
 const GnState* gn_result(suma_ctx* c);

@@ -18,7 +18,7 @@ def pytest_configure(config):
 # one late failure can never hide the per-kernel evidence again (round 5: a stopwatch assert in test_gpu_long.py stopped
 # the driver's run before test_gpu_parity.py had started).  Files not named here keep their alphabetical place between.
 _ORDER_FIRST = ["test_abi", "test_gpu_parity", "test_gpu_phases", "test_gpu_dist", "test_ref_golden", "test_golden",
-                "test_gpu_gl_golden", "test_gpu_cpp", "test_gpu_adapter"]
+                "test_gpu_gl_golden", "test_gpu_cpp", "test_ref_shells", "test_gpu_adapter"]
 _ORDER_LAST = ["test_gpu_long"]
 
 

@@ -631,10 +631,14 @@ def test_tiny_and_odd_image_sizes(hip, oracle_lib):
                 frames_equal(hp.frame(f), op.frame(f), f"{w}x{h} scan {k} frame {f}")
 
 
-def test_loop_closure_verification(hip, oracle_lib):
+@pytest.mark.parametrize("weight_function", [1, 2])
+def test_loop_closure_verification(hip, oracle_lib, weight_function):
     """device side of SurfelMapping::checkLoopClosure (SurfelMapping.cpp:662-757) against the same sequence
-    of oracle primitives: render_inactive -> 3 x (minimize, jacobianProducts, [render_composed, jacobianProducts])"""
-    p = params_with_size(900, max_iterations=8)
+    of oracle primitives: render_inactive -> 3 x (minimize, jacobianProducts, [render_composed, jacobianProducts]).
+    Frame2Model::iteration_ is reset by setData (:693, :719) only and counts on across the guesses (Frame2Model.cpp:
+    117-123, Objective.h:45-48): with the Tukey weight (2), which is off while iteration_ == 0
+    (Frame2Model_jacobians.geom:129), a later guess differs from a fresh minimisation from its first step."""
+    p = params_with_size(900, max_iterations=8, weight_function=weight_function)
     ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 4)
     # age the map: everything becomes "inactive" (creation stamp < timestamp - 100)
     surf = hmap.getAllSurfels()
@@ -660,9 +664,13 @@ def test_loop_closure_verification(hip, oracle_lib):
     ora.map_render_inactive(pose_prior.astype(np.float32), ct)
     model = ora.map_frame(0)
     n_passed = 0
+    it = 0  # Frame2Model::iteration_
+    fresh_differs = False
     for k, init in enumerate(inits):
-        T, _, st = ora.minimize(of, model, init)
-        it = st.iterations + (1 if st.converged else 0)
+        T, _, st = ora.minimize(of, model, init, iteration0=it)
+        if it > 0 and not np.array_equal(ora.minimize(of, model, init)[0], T):
+            fresh_differs = True
+        it += st.iterations + (1 if st.converged else 0)
         _, _, _, _, s0 = ora.jacobian_products(of, model, T, it)
         assert np.array_equal(res[k]["gn_pose"], T), f"guess {k} pose"
         a = res[k]["after_minimize"]
@@ -677,11 +685,15 @@ def test_loop_closure_verification(hip, oracle_lib):
             n_passed += 1
             ora.map_render_composed(pose_old, cur_pose.astype(np.float32), ct)
             model = ora.map_frame(2)   # the reference leaves the objective on the composed frame
+            it = 0                     # ... through setData, which resets iteration_
             Fc, _, JtJ, _, sc = ora.jacobian_products(of, model, np.eye(4), 0)
             c = res[k]["composed"]
             assert (c["valid"], c["outlier"], c["invalid"], c["error"]) == (sc.valid, sc.outlier, sc.invalid, sc.error)
             assert np.array_equal(res[k]["JtJ"], JtJ)
     assert n_passed >= 1, "test setup: at least one guess should pass the gates"
+    if weight_function == 2 and n_passed < len(inits):
+        assert fresh_differs, "test setup: the running iteration counter should matter to a Tukey-weighted later guess"
+    assert fresh_differs == (weight_function == 2 and fresh_differs)  # Huber never reads the counter
 
 
 def _same_loop_results(a, b, what):
@@ -693,8 +705,8 @@ def _same_loop_results(a, b, what):
             assert x[key] == y[key], f"{what}: guess {k} {key}: {x[key]} vs {y[key]}"
 
 
-@pytest.mark.parametrize("max_iterations", [8, 0])
-def test_batched_loop_closure_verification_equals_the_sequential_form(hip, oracle_lib, max_iterations):
+@pytest.mark.parametrize("max_iterations,weight_function", [(8, 1), (0, 1), (8, 2)])
+def test_batched_loop_closure_verification_equals_the_sequential_form(hip, oracle_lib, max_iterations, weight_function):
     """suma_loop_closure_verify runs the initial guesses of SurfelMapping.cpp:679-757 as ONE batched
     Gauss-Newton chain, speculatively against oldMapFrame(), and redoes the guesses behind the first one that passes
     against composedFrame() (the reference's setData at :718-719).  Whatever the order of the guesses and wherever the
@@ -702,7 +714,7 @@ def test_batched_loop_closure_verification_equals_the_sequential_form(hip, oracl
     guesses than one round would need -- the results are those of the literal one-by-one sequencing
     (suma_loop_closure_verify_serial, which test_loop_closure_verification's oracle sequence pins), bit for bit.
     max_iterations = 0 is the reference's "until convergence" mode (chunked launches, LieGaussNewton.cpp:27)."""
-    p = params_with_size(900, max_iterations=max_iterations)
+    p = params_with_size(900, max_iterations=max_iterations, weight_function=weight_function)
     ctx, ora, hmap = _run_maps(hip, oracle_lib, p, 900, 4)
     surf = hmap.getAllSurfels()
     hmap.upload(surf, 160)
