@@ -80,6 +80,10 @@ def usable_cpus():
     """CPUs this process may really use: the cgroup quota (cpu.max) where there is one, else the visible cores"""
     n = os.cpu_count() or 1
     try:
+        n = min(n, len(os.sched_getaffinity(0)))  # taskset / cpuset
+    except (AttributeError, OSError):
+        pass
+    try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
             n = min(n, max(1, int(float(q) / float(per))))
@@ -481,11 +485,13 @@ def main():
         pipe.runScans(host_warm, False, fixed_iterations=args.icp_iterations, call_seconds=warm_s)  # untimed, see HVW
         barrier()
         call_s = np.zeros(HV, dtype=np.float64)  # host time of each blocking call: shows a stall as what it is, one long call
+        pipe.hostEntryTimes(reset=True)
         th = time.perf_counter()
         assert pipe.runScans(host_job, False, fixed_iterations=args.icp_iterations, call_seconds=call_s) == HV
         barrier()
         th = time.perf_counter() - th
         per_call = call_s * 1e6
+        breakdown = pipe.hostEntryTimes()
         if world > 1:
             t = torch.tensor([th], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -496,6 +502,11 @@ def main():
                                     "calls_over_twice_the_median": int((per_call > 2.0 * np.median(per_call)).sum()),
                                     "first_30": [round(float(x), 1) for x in per_call[:30]],
                                     "untimed_warm_up_calls": [round(float(x) * 1e6, 1) for x in warm_s]},
+                        # where the caller's thread spent a call, averaged (us): waiting for the staging slot, copying
+                        # pageable -> pinned (copy_threads threads), enqueueing the upload, enqueueing kernels, and
+                        # waiting for the minimisation result (= the GPU is the bottleneck, as with resident scans)
+                        "call_breakdown_us": breakdown,
+                        "cpus": {"usable": usable_cpus(), "affinity": len(os.sched_getaffinity(0)), "visible": os.cpu_count()},
                         "entry": "suma_pipeline_process_scan: pageable host vectors -> pinned staging (8 cores) -> copy "
                                  "stream -> K1-K3 on the side stream; the PCIe-inclusive rate, same pipeline, the next "
                                  f"{HV} scans of the sequence, driven by the same native loop as the timed region"}

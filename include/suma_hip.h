@@ -348,6 +348,12 @@ typedef struct suma_kernel_time {
   double total_ms;
   double bytes; /* algorithmic bytes summed over the launches (SURVEY.md 8d formulas) */
 } suma_kernel_time;
+/* Where the calls of the blocking host-vector entry (suma_pipeline_process_scan / suma_pipeline_begin_scan: the
+ * reference's processScan(const rv::Laserscan&), SurfelMapping.cpp:175, 323-331) spent their time ON THE CALLER'S THREAD,
+ * summed since the last reset: out = {calls, whole calls, wait for the staging slot, pageable -> pinned copies, upload
+ * enqueue, kernel enqueue, wait for the minimisation result, threads that share the copies}; seconds.  The copy helpers
+ * are sized from the CPUs the process may use (affinity mask and cgroup quota; SUMA_COPY_HELPERS overrides). */
+int suma_pipeline_host_entry_times(suma_pipeline* s, double out[8], int reset);
 int suma_profile_enable(suma_ctx* ctx, int on);
 int suma_profile_reset(suma_ctx* ctx);
 int suma_profile_get(suma_ctx* ctx, suma_kernel_time* out, uint32_t cap);

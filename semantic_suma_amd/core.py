@@ -156,6 +156,7 @@ def lib():
     L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
     L.suma_map_download_cached_tile.argtypes = [vp, C.c_int32, C.c_int32, vp, u32, C.POINTER(u32)]
     L.suma_icp_set_iteration.argtypes = [vp, u32]
+    L.suma_pipeline_host_entry_times.argtypes = [vp, vp, C.c_int]
     L.suma_loop_closure_verify.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_loop_closure_verify_serial.argtypes = [vp, vp, vp, vp, u32, vp, f32, f32, f32, C.POINTER(LoopResult)]
     L.suma_pipeline_create.argtypes = [C.POINTER(SumaParams), C.c_int, pp]
@@ -835,6 +836,18 @@ class SurfelMapping:
     def prepareScans(self, scans, on_device: bool):
         refs, keep = _scan_refs(scans, on_device)
         return SequenceJob(refs, len(scans), 1 if on_device else 0), refs, keep
+
+    def hostEntryTimes(self, reset: bool = False):
+        """per-call averages (us) of where the blocking host-vector entry spends the CALLER's time
+        (suma_pipeline_host_entry_times)"""
+        out = np.zeros(8, dtype=np.float64)
+        self.ctx.check(self.L.suma_pipeline_host_entry_times(self.h, _ptr(out), int(reset)), "suma_pipeline_host_entry_times")
+        n = max(out[0], 1.0)
+        keys = ("call", "slot_wait", "copy", "upload_enqueue", "kernel_enqueue", "result_wait")
+        d = {k: round(1e6 * float(v) / n, 1) for k, v in zip(keys, out[1:7])}
+        d["calls"] = int(out[0])
+        d["copy_threads"] = int(out[7])
+        return d
 
     def processScanDevice(self, d_points: int, d_labels: int, d_probs: int, n: int, fixed_iterations: int = 0):
         """scan already resident in HBM (device addresses from Context.device_array)"""

@@ -11,6 +11,8 @@
 #include <new>
 #include <set>
 
+#include <time.h>
+
 #include "suma_internal.h"
 
 /* contexts that are alive: a frame may outlive its context (callers destroy in any order), so suma_frame_destroy asks
@@ -289,6 +291,8 @@ extern "C" int suma_ctx_create(const suma_params* params, int hip_device, suma_c
   }
   c->p = *params;
   c->device = hip_device;
+  memset(&c->het, 0, sizeof(c->het));
+  c->icp_iteration0 = 0;
   c->profiling = 0;
   c->prof_tick = 0;
   c->epoch = 0;
@@ -1882,7 +1886,11 @@ static int update_pose(suma_pipeline* s, int32_t fixed_iterations) {
     c->k8_fused_params = c->params_version;
   }
   /* --- wait for the minimisation result only (poll on the record's sequence number) --- */
+  struct timespec tw0, tw1;
+  clock_gettime(CLOCK_MONOTONIC, &tw0);
   int r = wait_host_result(c, &s->h_res[0], s->res_seq);
+  clock_gettime(CLOCK_MONOTONIC, &tw1);
+  c->het.result_wait_s += (double)(tw1.tv_sec - tw0.tv_sec) + 1e-9 * (double)(tw1.tv_nsec - tw0.tv_nsec);
   if (r) return r;
   r = resolve_stats(s, false); /* the previous scan's statistics launch precedes this result in the stream */
   if (r) return r;

@@ -35,6 +35,9 @@
 
 #include "suma_internal.h"
 
+#include <sched.h>
+#include <stdio.h>
+
 #define INGEST_SLOTS 3u
 
 struct IngestSlot {
@@ -65,6 +68,7 @@ struct CopySeg {
   size_t bytes;
 };
 struct CopyPool {
+  int helpers; /* helper threads that exist (0 .. COPY_HELPERS): sized from the CPUs this process may use */
   std::mutex mu;
   std::condition_variable cv;
   std::vector<std::thread> th;
@@ -113,9 +117,9 @@ static void copy_helper(CopyPool* p, int id) {
   }
 }
 
-/* share `part` (0 = the caller) of a segment split into COPY_HELPERS + 1 page-aligned shares */
-static CopySeg seg_share(const CopySeg& s, int part) {
-  const size_t parts = COPY_HELPERS + 1;
+/* share `part` (0 = the caller) of a segment split into helpers + 1 page-aligned shares */
+static CopySeg seg_share(const CopySeg& s, int part, int helpers) {
+  const size_t parts = (size_t)helpers + 1;
   const size_t share = ((s.bytes / parts) + 4095) & ~(size_t)4095;
   const size_t lo = share * (size_t)part;
   if (s.bytes == 0 || lo >= s.bytes) return {nullptr, nullptr, 0};
@@ -132,16 +136,17 @@ static void pool_copy(CopyPool* p, const CopySeg* segs, int nseg) {
       if (segs[k].bytes) memcpy(segs[k].dst, segs[k].src, segs[k].bytes);
     return;
   }
-  for (int h = 0; h < COPY_HELPERS; ++h)
-    for (int k = 0; k < COPY_SEGMENTS; ++k) p->job[h][k] = (k < nseg) ? seg_share(segs[k], h + 1) : CopySeg{nullptr, nullptr, 0};
-  p->pending.store(COPY_HELPERS, std::memory_order_relaxed);
+  const int H = p->helpers;
+  for (int h = 0; h < H; ++h)
+    for (int k = 0; k < COPY_SEGMENTS; ++k) p->job[h][k] = (k < nseg) ? seg_share(segs[k], h + 1, H) : CopySeg{nullptr, nullptr, 0};
+  p->pending.store(H, std::memory_order_relaxed);
   p->posted.fetch_add(1, std::memory_order_release);
   if (p->sleepers.load() > 0) {
     std::lock_guard<std::mutex> lk(p->mu); /* pairs with the predicate check of a helper about to sleep */
     p->cv.notify_all();
   }
   for (int k = 0; k < nseg; ++k) {
-    const CopySeg mine = seg_share(segs[k], 0);
+    const CopySeg mine = seg_share(segs[k], 0, H);
     if (mine.bytes) memcpy(mine.dst, mine.src, mine.bytes);
   }
   while (p->pending.load(std::memory_order_acquire) != 0) __builtin_ia32_pause();
@@ -226,6 +231,34 @@ static void ingest_main(Ingest* g) {
   }
 }
 
+/* CPUs this process may use: the smaller of the affinity mask and the cgroup v2 quota (cpu.max = "quota period") */
+static int usable_cpus() {
+  int n = 0;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (int)std::thread::hardware_concurrency();
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    double period = 0.0;
+    if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0.0) {
+      const int quota = (int)(atof(q) / period + 0.5);
+      if (quota >= 1 && quota < n) n = quota;
+    }
+    fclose(f);
+  }
+  return n > 0 ? n : 1;
+}
+static int ingest_default_helpers() {
+  const int n = usable_cpus();
+  /* Half of what is left beside the caller (the other half stays with the application's own threads), three at most:
+   * 8 CPUs and more -> 3 helpers, 4 -> 1, 2 -> 0.  Measured on the pool's box under taskset
+   * (profiles/r06_host_entry_cpus.jsonl): the 3 MB of a 64 x 2048 scan take 88 us on the caller alone, 65 with one
+   * helper, 62 with three, 50 with seven -- every helper beyond the third buys 3 us and spins a CPU for it. */
+  const int h = (n - 1) / 2;
+  return h > 3 ? 3 : h;
+}
+
 static int ingest_get(suma_ctx* c, Ingest** out) {
   if (c->ingest) {
     *out = c->ingest;
@@ -254,11 +287,19 @@ static int ingest_get(suma_ctx* c, Ingest** out) {
     HIP_TRY(c, hipEventCreateWithFlags(&q.uploaded, hipEventDisableTiming));
     HIP_TRY(c, hipEventCreateWithFlags(&q.consumed, hipEventDisableTiming));
   }
-  /* SUMA_COPY_HELPERS=0: the caller copies alone (hosts that cannot spare cores) */
+  /* Helper threads for the pageable -> pinned copy, sized from the CPUs this process may really use: the affinity mask
+   * AND the cgroup's CPU quota (a GPU box of the pool shows 256 cores and grants 16; the round-5 driver run lost 11 % of
+   * the host-vector rate with eight copying threads next to pytest's own).  A helper SPINS between scans (SPIN_NS), so
+   * each one is a CPU taken: one CPU stays with the caller, one with the rest of the process, at most COPY_HELPERS
+   * help.  SUMA_COPY_HELPERS=n overrides (0: the caller copies alone). */
+  int helpers = ingest_default_helpers();
   const char* nh = getenv("SUMA_COPY_HELPERS");
-  const int helpers = nh ? atoi(nh) : COPY_HELPERS;
-  if (helpers > 0)
-    for (int h = 0; h < COPY_HELPERS; ++h) g->pool.th.emplace_back(copy_helper, &g->pool, h);
+  if (nh) helpers = atoi(nh);
+  if (helpers < 0) helpers = 0;
+  if (helpers > COPY_HELPERS) helpers = COPY_HELPERS;
+  g->pool.helpers = helpers;
+  for (int h = 0; h < helpers; ++h) g->pool.th.emplace_back(copy_helper, &g->pool, h);
+  c->het.copy_threads = (uint32_t)helpers + 1u;
   g->worker = std::thread(ingest_main, g);
   c->ingest = g;
   *out = g;
@@ -433,8 +474,11 @@ int ingest_stage_blocking(suma_ctx* c, const suma_float4* points, const float* l
     }
   }
   IngestSlot* q = &g->bslot[g->bnext++ & 1u];
+  long long t0 = mono_ns();
   if (q->consumed_valid) HIP_TRY(c, hipEventSynchronize(q->consumed)); /* the scan before last has read this slot */
   HIP_TRY(c, slot_reserve(g, q, n));
+  long long t1 = mono_ns();
+  c->het.slot_wait_s += 1e-9 * (double)(t1 - t0);
   if (n > 0) {
     size_t bytes = (size_t)n * sizeof(float4);
     if (labels) bytes = labels_offset(n) + (size_t)n * sizeof(float);
@@ -457,10 +501,15 @@ int ingest_stage_blocking(suma_ctx* c, const suma_float4* points, const float* l
         if (part[k].len && a < b) ps[np++] = {q->pinned + a, part[k].src + (a - part[k].off), b - a};
       }
       pool_copy(&g->pool, ps, np);
+      const long long t2 = mono_ns();
+      c->het.copy_s += 1e-9 * (double)(t2 - t1);
       HIP_TRY(c, hipMemcpyAsync(q->device + lo, q->pinned + lo, hi - lo, hipMemcpyHostToDevice, g->copy_stream));
+      t1 = mono_ns();
+      c->het.enqueue_s += 1e-9 * (double)(t1 - t2);
     }
   }
   HIP_TRY(c, hipEventRecord(q->uploaded, g->copy_stream));
+  c->het.enqueue_s += 1e-9 * (double)(mono_ns() - t1);
   *d_points = (const suma_float4*)q->device;
   *d_labels = labels ? (const float*)(q->device + labels_offset(n)) : nullptr;
   *d_probs = probs ? (const float*)(q->device + probs_offset(n)) : nullptr;
@@ -468,6 +517,27 @@ int ingest_stage_blocking(suma_ctx* c, const suma_float4* points, const float* l
   *slot = (void*)q;
   return SUMA_OK;
 }
+/* where the calls of the blocking host-vector entry spent their time on the caller's thread, as sums since the last
+ * reset: out = {calls, call, slot wait, copy, upload enqueue, kernel enqueue, result wait, copy threads} (seconds) */
+extern "C" int suma_pipeline_host_entry_times(suma_pipeline* s, double out[8], int reset) {
+  if (!s || !out) return SUMA_ERR_INVALID;
+  HostEntryTimes& h = s->c->het;
+  out[0] = (double)h.calls;
+  out[1] = h.call_s;
+  out[2] = h.slot_wait_s;
+  out[3] = h.copy_s;
+  out[4] = h.enqueue_s;
+  out[5] = h.launch_s;
+  out[6] = h.result_wait_s;
+  out[7] = (double)h.copy_threads;
+  if (reset) {
+    const uint32_t t = h.copy_threads;
+    memset(&h, 0, sizeof(h));
+    h.copy_threads = t;
+  }
+  return SUMA_OK;
+}
+
 void ingest_consumed(suma_ctx* c, void* slot, hipStream_t reader) {
   IngestSlot* q = (IngestSlot*)slot;
   (void)c;
@@ -484,6 +554,8 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
   const float *dl, *dq;
   hipEvent_t up;
   void* slot;
+  const long long t_call = mono_ns();
+  const double waits_before = c->het.slot_wait_s + c->het.copy_s + c->het.enqueue_s + c->het.result_wait_s;
   int r = ingest_stage_blocking(c, points, labels, probs, n, &dp, &dl, &dq, &up, &slot);
   if (r) return r;
   r = pipeline_begin_scan_impl(s, dp, dl, dq, n, up);
@@ -493,6 +565,10 @@ static int run_host_scan(suma_pipeline* s, const suma_float4* points, const floa
     if (r == SUMA_OK) r = pipeline_update_map_impl(s);
   }
   if (r != SUMA_OK) s->phase = 0;
+  const double dt = 1e-9 * (double)(mono_ns() - t_call);
+  c->het.call_s += dt;
+  c->het.calls += 1;
+  c->het.launch_s += dt - ((c->het.slot_wait_s + c->het.copy_s + c->het.enqueue_s + c->het.result_wait_s) - waits_before);
   return r;
 }
 int pipeline_process_host_scan(suma_pipeline* s, const suma_float4* points, const float* labels, const float* probs,

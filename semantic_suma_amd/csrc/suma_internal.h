@@ -111,6 +111,19 @@ struct ProfEvent {
   uint32_t launches; /* kernel launches bracketed by this event pair (a chain of identical launches) */
 };
 
+/* host-side time of the blocking host-vector entry (suma_pipeline_process_scan), summed since the last reset:
+ * where a call of the reference-shaped entry spends its time on the CALLER's thread (suma_pipeline_host_entry_times) */
+struct HostEntryTimes {
+  double slot_wait_s;  /* waiting for the staging slot of the scan before last to be read */
+  double copy_s;       /* pageable -> pinned copies (caller + helper threads) */
+  double enqueue_s;    /* hipMemcpyAsync + event record of the upload */
+  double launch_s;     /* enqueueing the scan's kernels (everything else that is not a wait) */
+  double result_wait_s; /* polling for the minimisation result: the GPU is the one being waited for */
+  double call_s;       /* whole calls */
+  uint64_t calls;
+  uint32_t copy_threads; /* caller + helpers that took a share of the copies */
+};
+
 struct suma_ctx {
   suma_params p;
   int device;
@@ -175,6 +188,7 @@ struct suma_ctx {
   float* pose_block;       /* device: 16 floats pose + 16 floats inverse for the post-ICP render */
   int gn_init_pending; /* the next k_icp_iter launch starts a fresh single chain from gn_T0_host */
   uint32_t gn_iteration0;
+  HostEntryTimes het;
   uint32_t icp_iteration0; /* suma_icp_set_iteration: Frame2Model::iteration_ for the NEXT suma_icp_minimize (one shot) */
   double gn_T0_host[16];
   double* gn_history;  /* (max_iterations + 1) x 16 doubles (single minimise only) */
