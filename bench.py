@@ -351,7 +351,7 @@ def main():
                       "devices": sorted(set(_all_devices(dist, world, local_rank, coll_dev)))}
 
     from semantic_suma_amd import core, synth
-    from semantic_suma_amd.distributed import gather_poses
+    from semantic_suma_amd.distributed import NativeGather, gather_poses
     from semantic_suma_amd.types import params_with_size
 
     W, H, K, Wu = args.width, args.height, args.steps, args.warmup
@@ -373,6 +373,20 @@ def main():
     p = params_with_size(W, H, label_offset=0, prob_offset=0, **extra) if kitti_dir else params_with_size(W, H, **extra)
     pipe = core.SurfelMapping(p, device=local_rank)
     ctx = pipe.ctx
+    # ONE collective path for the data: the pose gather of an N-GPU run goes through the C-ABI export of SURVEY.md 8(b)
+    # (suma_gather_poses, libsuma_hip_dist.so: an RCCL all-gather on the ctx stream); torch.distributed bootstraps it and
+    # carries the launcher's barriers and the max-over-ranks clock.  gloo runs (CPU tests, several ranks on one device:
+    # RCCL refuses that) and a rank that cannot create its communicator use torch.distributed, and the line says so.
+    native = NativeGather(ctx, device=coll_dev) if (world > 1 and args.backend == "nccl") else None
+    if native is not None and not native.ok:
+        print(f"bench.py: native pose gather unavailable ({native.error}); using torch.distributed", file=sys.stderr)
+    args.dist_info["pose_gather"] = ("libsuma_hip_dist.so: suma_gather_poses (RCCL all-gather on the ctx stream)"
+                                     if native is not None and native.ok else
+                                     ("torch.distributed all_gather (" + (native.error if native is not None else
+                                      f"backend {args.backend}") + ")") if world > 1 else None)
+
+    def gather_pose(a):
+        return native.gather(a) if native is not None and native.ok else gather_poses(a, device=coll_dev)
 
     # ---- synthetic sequence of this rank (its own stretch of the trajectory), uploaded to HBM
     # Order of a run: Wu warm-up scans | K scans timed from the cold start (extra key `cold_start`) | untimed pre-roll
@@ -457,7 +471,7 @@ def main():
     assert pipe.runScans(timed_job, True, fixed_iterations=args.icp_iterations, call_seconds=timed_call_s) == K
     ctx.synchronize()
     own = time.perf_counter() - t0  # this rank's scans alone: everything behind it is waiting for the slowest rank
-    poses = gather_poses(pipe.getCurrentPose(), device=coll_dev) if world > 1 else None
+    poses = gather_pose(pipe.getCurrentPose()) if world > 1 else None
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = None

@@ -77,6 +77,78 @@ def gather_poses(local: np.ndarray, device=None) -> np.ndarray:
     return np.stack([o.cpu().numpy() for o in outs])
 
 
+class NativeGather:
+    """The gather of SURVEY.md 8(b) -- `suma_gather_poses` / `suma_gather` of libsuma_hip_dist.so: one RCCL all-gather on
+    the ctx stream -- for a job whose ranks were started by torch.distributed.  torch.distributed only BOOTSTRAPS it (rank
+    0's 128-byte RCCL id is broadcast over the existing process group, as a C++ host would send it over MPI or a socket)
+    and carries the launcher's barrier; the data-path collective is the library's own.  Every rank must construct it at
+    the same point.  `ok` is False (with `error`) on every rank if any rank failed to create its communicator."""
+
+    def __init__(self, ctx, device=None):
+        import ctypes as C
+        import os
+
+        import torch
+        import torch.distributed as dist
+
+        from . import core
+        self.ctx, self.comm, self.ok, self.error = ctx, None, False, ""
+        self.world, self.rank = dist.get_world_size(), dist.get_rank()
+        vp = C.c_void_p
+        uid = torch.zeros(128, dtype=torch.uint8, device=device)
+        flag = 1
+        try:
+            D = C.CDLL(os.path.join(os.path.dirname(core.LIB_PATH), "libsuma_hip_dist.so"))
+            D.suma_dist_unique_id.argtypes = [vp]
+            D.suma_dist_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+            D.suma_dist_comm_destroy.argtypes = [vp]
+            D.suma_gather_poses.argtypes = [vp, vp, vp, vp]
+            D.suma_gather.argtypes = [vp, vp, vp, C.c_uint32, vp]
+            D.suma_dist_last_error.restype = C.c_char_p
+            D.suma_dist_last_error.argtypes = [vp]
+            self.D = D
+            if self.rank == 0:
+                buf = C.create_string_buffer(128)
+                if D.suma_dist_unique_id(buf) != 0:
+                    raise RuntimeError("suma_dist_unique_id: " + D.suma_dist_last_error(None).decode())
+                uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).to(uid.device)
+        except (OSError, RuntimeError) as e:  # the library is missing or RCCL refused: every rank must learn it
+            flag, self.error = 0, repr(e)
+        ok = torch.tensor([flag], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)  # nobody enters ncclCommInitRank unless everybody can
+        if int(ok.item()) == 0:
+            self.error = self.error or "another rank could not load libsuma_hip_dist.so"
+            return
+        dist.broadcast(uid, src=0)
+        comm = vp()
+        buf = C.create_string_buffer(bytes(uid.cpu().numpy().tobytes()), 128)
+        rc = self.D.suma_dist_comm_create(buf, self.world, self.rank, C.byref(comm))
+        ok = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if rc != 0:
+            self.error = "suma_dist_comm_create: " + self.D.suma_dist_last_error(None).decode()
+        elif int(ok.item()) == 0:
+            self.error = "suma_dist_comm_create failed on another rank"
+            self.D.suma_dist_comm_destroy(comm)
+        else:
+            self.comm, self.ok = comm, True
+
+    def gather(self, local: np.ndarray) -> np.ndarray:
+        """all-gather of <= 64 doubles per rank behind everything enqueued on the ctx -> [world, ...]"""
+        a = np.ascontiguousarray(local, dtype=np.float64)
+        out = np.zeros((self.world,) + a.shape, dtype=np.float64)
+        rc = (self.D.suma_gather_poses(self.ctx.h, self.comm, a.ctypes.data, out.ctypes.data) if a.size == 16 else
+              self.D.suma_gather(self.ctx.h, self.comm, a.ctypes.data, a.size, out.ctypes.data))
+        if rc != 0:
+            raise RuntimeError("suma_gather: " + self.D.suma_dist_last_error(self.comm).decode())
+        return out
+
+    def close(self):
+        if self.comm is not None:
+            self.D.suma_dist_comm_destroy(self.comm)
+            self.comm = None
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # GPU-side runners for BASELINE configs 3 and 4.  They are written against a small engine interface so that the very
 # same orchestration code runs over the HIP path (HipEngine below) and, in the world-2 gloo tests on CPU, over a

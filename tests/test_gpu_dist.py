@@ -176,7 +176,8 @@ def test_bench_launches_two_ranks_by_itself():
 def test_rccl_process_group_beside_the_pipeline():
     """What every rank of `bench.py --gpus N` (N > 1) does, with N = 1: a torch.distributed process group on RCCL
     (backend "nccl") lives in the same process as libsuma_hip.so, collectives on CUDA tensors (barrier, all_reduce
-    MAX, all_gather of poses) run between scans, and the pipeline's results do not change.  Fresh interpreter, torch
+    MAX, all_gather of poses) run between scans, the native pose gather (libsuma_hip_dist.so, bootstrapped over the
+    process group) returns the pose, and the pipeline's results do not change.  Fresh interpreter, torch
     first -- the order bench.py uses (one HIP runtime in the process)."""
     import subprocess
     code = f"""
@@ -205,6 +206,15 @@ for s in scans:
     outs = [torch.empty_like(x)]
     dist.all_gather(outs, x)
     assert np.array_equal(outs[0].cpu().numpy(), pipe.getCurrentPose())
+# the pose gather bench.py --gpus N uses for N > 1: suma_gather_poses of libsuma_hip_dist.so (the SURVEY 8(b) export),
+# bootstrapped over this process group -- here with the one rank a 1-GPU box can host
+from semantic_suma_amd.distributed import NativeGather
+ng = NativeGather(pipe.ctx, device=dev)
+assert ng.ok, ng.error
+g = ng.gather(pipe.getCurrentPose())
+assert g.shape == (1, 4, 4) and np.array_equal(g[0], pipe.getCurrentPose())
+assert np.array_equal(ng.gather(np.arange(5.0))[0], np.arange(5.0))
+ng.close()
 torch.cuda.synchronize()
 assert np.array_equal(pipe.getCurrentPose(), want), "pose changed beside the process group"
 assert pipe.map.getAllSurfels().tobytes() == solo.map.getAllSurfels().tobytes()
