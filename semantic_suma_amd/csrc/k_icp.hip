@@ -902,6 +902,16 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
   if (writer) gout->pending = 1;
 }
 
+/* Where IterArgs lies in the kernel-argument segment of the two entry points below (gn_args_again): behind N leading
+ * pointers, at the next multiple of its own alignment -- written as what the ABI computes, and pinned, so that a new
+ * leading parameter or a wider member of IterArgs cannot silently make the launches read another matrix as T0
+ * (round-5 advisor; both paths are covered by the Gauss-Newton parity tests: T0 by the first launch of every chain,
+ * pose_base by the scan pipeline's closing launch). */
+#define GN_KARG_OFFSET(n_leading_pointers) \
+  ((uint32_t)(((n_leading_pointers) * sizeof(void*) + alignof(IterArgs) - 1) / alignof(IterArgs) * alignof(IterArgs)))
+static_assert(alignof(IterArgs) == 8 && sizeof(void*) == 8, "IterArgs follows the leading pointers without padding");
+static_assert(GN_KARG_OFFSET(5) == 40u && GN_KARG_OFFSET(2) == 16u, "kernarg offsets of k_icp_step / k_icp_finish");
+
 /* two entry points so that profiles tell the pixel launches from the closing consume-only launch */
 /* The pointers behind a launch's FIRST loads are leading scalar parameters: with kernarg preloading (Makefile:
  * -amdgpu-kernarg-preload-count) they arrive in SGPRs with the wave, so the record / state / data-texel loads of the
@@ -913,12 +923,12 @@ __global__ void __launch_bounds__(ICP_THREADS)
   g.a.Vd = Vd;
   g.a.Nd = Nd;
   g.a.Sd = Sd;
-  icp_iter_body<true>(g, 40u); /* five leading pointers, then IterArgs */
+  icp_iter_body<true>(g, GN_KARG_OFFSET(5)); /* five leading pointers, then IterArgs */
 }
 __global__ void __launch_bounds__(ICP_THREADS) k_icp_finish(const long long* pin, const GnState* gin, IterArgs g) {
   g.pin = pin;
   g.gin = gin;
-  icp_iter_body<false>(g, 16u); /* two leading pointers, then IterArgs */
+  icp_iter_body<false>(g, GN_KARG_OFFSET(2)); /* two leading pointers, then IterArgs */
 }
 
 static IcpArgs make_args(suma_ctx* c) {

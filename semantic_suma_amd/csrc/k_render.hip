@@ -628,7 +628,10 @@ static void set_m4(m4& d, const float* s) {
 
 /* the instantiation for this model image (see the row / column split in phase 2) */
 static void run_render(suma_ctx* c, const RenderArgs& a, uint32_t grid) {
-  if (c->Pm >= ((size_t)1 << 21))
+  /* decided on the image THIS launch renders into (a.q), which is what bounds q in phase 2; the rasteriser's other
+   * range precondition -- window coordinates |X| < 2^21 in 1/256 pixel, x01 in [-0.5, 1.5] -- is a limit on the model
+   * width that suma_ctx_create / suma_set_params enforce (SUMA_MAX_MODEL_WIDTH) */
+  if ((size_t)a.q.W * (size_t)a.q.H >= ((size_t)1 << 21))
     k_render<true><<<grid, RENDER_THREADS, 0, c->ls>>>(a);
   else
     k_render<false><<<grid, RENDER_THREADS, 0, c->ls>>>(a);

@@ -253,6 +253,11 @@ static const char* filter_params_error(const suma_params* p) {
   if (p->filter_vertexmap && !(p->bilateral_sigma_space > 0.0f && p->bilateral_sigma_range > 0.0f))
     return "filter_vertexmap needs bilateral_sigma_space and bilateral_sigma_range > 0 (config/default.xml holds no "
            "bilateral_sigma_space; Preprocessing.cpp:86 would throw on the missing key)";
+  /* k_render.hip keeps window coordinates in 1/256 pixel with |X| < 2^21 (x01 in [-0.5, 1.5] for a quad across the
+   * seam): 1.5 * 256 * W < 2^21; its edge functions and exact barycentric divisions are proven on that range */
+  if (p->model_width > SUMA_MAX_MODEL_WIDTH)
+    return "model_width above 5461 columns is outside the range of the rasteriser's fixed-point window coordinates "
+           "(k_render.hip: |X| < 2^21 in 1/256 pixel)";
   if ((p->filter_vertexmap || p->avg_vertexmap) && (p->data_width > 8192 || p->data_height > 8192))
     return "avg_vertexmap / filter_vertexmap: images above 8192 texels per side are not covered (k_filters.hip)";
   return nullptr;

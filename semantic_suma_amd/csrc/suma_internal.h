@@ -27,6 +27,7 @@
 #endif
 #define SUMA_STREAM_BLOCKS 2048u /* grid cap of the grid-stride surfel kernels: 8 blocks of 256 per CU */
 #define SUMA_EXTRACT_CAPACITY 500000u /* SurfelMap.cpp:279 */
+#define SUMA_MAX_MODEL_WIDTH 5461u /* floor((2^21 - 1) / (1.5 * 256)): k_render's window coordinates */
 #define SUMA_MAX_HYP 64u
 
 /* Counters that live in HBM so that no kernel launch needs a host round trip. */

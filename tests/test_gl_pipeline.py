@@ -32,8 +32,24 @@ def glp():
     return glpipeline
 
 
-def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
-    """THE ACCEPTANCE LINE.  Teacher-forced, per ICP iteration: from the oracle's pose before iteration k, ONE Gauss-Newton
+@pytest.mark.parametrize("which", ["driver", "detmath"])
+def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib, which):
+    """Teacher-forced, per ICP iteration, in two variants (round-5 advisor: both are kept side by side).
+
+    "driver" -- the reference GL path AS SHIPPED: the reference's shader text and the GL implementation's own asin / acos /
+    atan (Mesa llvmpipe here; no vendor GL exists on either machine).  This is the check that does not depend on anything
+    this repository specifies.  Asserted at the bounds it has carried since round 4: every step within 2e-3 m / 3e-4 rad of
+    the oracle's, the median within 3e-4 m / 5e-5 rad.  north_star's 1e-4 m / 1e-5 rad is NOT met against it (32 of 40
+    steps are beyond 1e-4 m): llvmpipe's asin is up to 3.9e-4 rad off -- GLSL leaves the accuracy of the angle functions
+    to the implementation -- and moves ~10 pairs per iteration across a gate (tests/test_gl_controls.py).
+
+    "detmath" -- a CONTROL, not the reference as shipped: the same shader text with its three angle functions #defined to
+    the specified ones (oracle/glref.py::DETMATH_PRELUDE, checked bit for bit against include/suma_detmath.h), i.e. both
+    sides share their transcendentals and what remains is everything else a real GL does (rasterisation, fp32 blending
+    in draw order, texture filtering).  Here the acceptance tolerance holds with a margin of 70: the claim is "within
+    1e-4 m / 1e-5 rad per iteration of the reference's shader text UNDER SPECIFIED TRANSCENDENTALS".
+
+    Per step: from the oracle's pose before iteration k, ONE Gauss-Newton
     step with the reference's Frame2Model_jacobians shaders executed by llvmpipe, on the oracle's frames, against the
     oracle's pose after iteration k -- the pose the HIP path reproduces bit for bit.  north_star: "pose delta within
     1e-4 m / 1e-5 rad per ICP iteration" of the reference OpenGL path.
@@ -46,7 +62,7 @@ def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
     implementation): every one of the 40 steps is asserted within 1e-4 m / 1e-5 rad (measured: 3e-7 m / 3e-8 rad)."""
     p = params_with_size(W)
     op = oracle_lib.OraclePipeline(p, threads=max(1, min(8, os.cpu_count() or 1)))
-    with glp.gl.transcendentals("detmath"):
+    with glp.gl.transcendentals(which):
         k6 = glp.gl.Jacobians(p)
     steps = []
     for k in range(5):
@@ -76,8 +92,14 @@ def test_per_iteration_pose_increments_of_the_gl_path(glp, oracle_lib):
         print("scan %d it %d: %.2e m %.2e rad (%d pairs)" % row)
     dts, drs = np.array([r[2] for r in steps]), np.array([r[3] for r in steps])
     assert len(steps) == 40
-    assert dts.max() <= 1e-4 and drs.max() <= 1e-5, (dts.max(), drs.max())
-    print(f"per-iteration GL vs oracle, worst of {len(steps)} steps: {dts.max():.2e} m / {drs.max():.2e} rad")
+    print(f"per-iteration GL ({which} transcendentals) vs oracle, worst of {len(steps)} steps: {dts.max():.2e} m / "
+          f"{drs.max():.2e} rad, median {np.median(dts):.2e} m / {np.median(drs):.2e} rad, "
+          f"{int((dts > 1e-4).sum())} steps beyond 1e-4 m")
+    if which == "detmath":
+        assert dts.max() <= 1e-4 and drs.max() <= 1e-5, (dts.max(), drs.max())
+    else:
+        assert dts.max() <= 2e-3 and drs.max() <= 3e-4, (dts.max(), drs.max())
+        assert np.median(dts) <= 3e-4 and np.median(drs) <= 5e-5, (np.median(dts), np.median(drs))
 
 
 def test_free_running_gl_pipeline_against_the_oracle(glp, oracle_lib):

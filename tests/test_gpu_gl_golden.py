@@ -74,7 +74,9 @@ def test_acceptance_line_hip_against_the_reference_gl_path_per_iteration():
     Frame2Model_jacobians shaders executed by a real OpenGL (llvmpipe; the shader text unchanged, asin / acos / atan from
     the specified functions).  Here the HIP path runs the same teacher-forced minimisations: its pose before every
     iteration must equal the stored one BIT FOR BIT (so both sides stepped from the same state on the same frames), and
-    its pose after the iteration must lie within the tolerance of the GL path's (measured: 1.5e-6 m / 1.1e-7 rad)."""
+    its pose after the iteration must lie within the tolerance of the GL path's (measured: 1.5e-6 m / 1.1e-7 rad).
+    That is the claim "within tolerance of the reference's shader text under specified transcendentals"; the same steps
+    with the GL implementation's own transcendentals (pose_after_gl_driver) are compared at their round-4 bounds."""
     import math
     from conftest import get_scan
     from semantic_suma_amd import core
@@ -86,6 +88,7 @@ def test_acceptance_line_hip_against_the_reference_gl_path_per_iteration():
     pre, obj, gn = core.Preprocessing(ctx), core.Frame2Model(ctx), core.LieGaussNewton(ctx)
     cur, out = core.Frame(ctx, W, H), core.Frame(ctx, p.model_width, p.model_height)
     row, worst = 0, (0.0, 0.0)
+    driver = []  # against the same steps with the GL implementation's OWN asin / acos / atan (the reference as shipped)
     for k in range(n):
         pts, lab, prob, _ = get_scan(k, W, True)
         if k >= 1:
@@ -106,7 +109,16 @@ def test_acceptance_line_hip_against_the_reference_gl_path_per_iteration():
                 dr = math.acos(max(-1.0, min(1.0, 0.5 * (np.trace(D[:3, :3]) - 1.0))))
                 assert dt <= 1e-4 and dr <= 1e-5, f"scan {k} iteration {it}: {dt:.2e} m / {dr:.2e} rad from the reference GL path"
                 worst = (max(worst[0], dt), max(worst[1], dr))
+                D = np.linalg.inv(z["pose_after_gl_driver"][row]) @ hist[it + 1]
+                driver.append((float(np.linalg.norm(D[:3, 3])), math.acos(max(-1.0, min(1.0, 0.5 * (np.trace(D[:3, :3]) - 1.0))))))
                 row += 1
         hp.processScan(pts, lab, prob, fixed_iterations=iters)
     assert row == z["pose_before"].shape[0] == 40
     print(f"HIP vs the reference's shaders in OpenGL, per ICP iteration: worst {worst[0]:.2e} m / {worst[1]:.2e} rad over {row} iterations")
+    # The reference GL path AS SHIPPED (llvmpipe's own transcendentals; its asin is up to 3.9e-4 rad off and moves ~10 pairs
+    # per iteration across a gate): the bounds this comparison has carried since round 4 -- every step within 2e-3 m /
+    # 3e-4 rad, the median within 3e-4 m / 5e-5 rad.  The 1e-4 m / 1e-5 rad above holds under SPECIFIED transcendentals.
+    dts, drs = np.array([d[0] for d in driver]), np.array([d[1] for d in driver])
+    print(f"  with the GL driver's own transcendentals: worst {dts.max():.2e} m / {drs.max():.2e} rad, median {np.median(dts):.2e} m / "
+          f"{np.median(drs):.2e} rad, {int((dts > 1e-4).sum())} of {len(dts)} steps beyond 1e-4 m")
+    assert dts.max() <= 2e-3 and drs.max() <= 3e-4 and np.median(dts) <= 3e-4 and np.median(drs) <= 5e-5

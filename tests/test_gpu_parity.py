@@ -139,6 +139,14 @@ def test_vertexmap_filter_parameter_errors(hip):
     ctx = hip.Context(params_with_size(900))
     with pytest.raises(hip.SumaError, match="bilateral_sigma_space"):
         ctx.set_params(params_with_size(900, filter_vertexmap=1))
+    # the rasteriser's fixed-point window coordinates (|X| < 2^21 in 1/256 pixel) bound the model width; the range is
+    # enforced, not assumed (round-5 advisor)
+    wide = params_with_size(900)
+    wide.model_width = 5462
+    with pytest.raises(hip.SumaError, match="model_width"):
+        hip.Context(wide)
+    with pytest.raises(hip.SumaError, match="fixed at creation"):  # and a context's image sizes cannot be changed later
+        ctx.set_params(wide)
 
 
 def test_preprocess_edge_cases(hip, oracle_lib):
