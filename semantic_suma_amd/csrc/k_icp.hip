@@ -28,6 +28,8 @@
  *     round trip.  The closing launch (k_icp_finish, one block) only consumes and reports into a pinned host
  *     record; the objective-only statistics pass closes itself (last block totals and reports).
  */
+#include <cstddef>
+
 #include "suma_internal.h"
 
 /* -DSUMA_GN_TIMING (tools/gn_timeline.py builds such a library next to the product one): every block stamps
@@ -625,35 +627,34 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
     gout->converged = 0;
     gout->done = 0;
     gout->valid = gout->outlier = gout->invalid = 0;
-  } else if (writer) {
-    /* nothing to consume: carry the state over to the other buffer */
-    for (int i = 0; i < 16; ++i) gout->Tk[i] = Tk[i];
-    gout->last_error = gin->last_error;
-    gout->F = gin->F;
-    gout->F_inlier = gin->F_inlier;
-    gout->iteration = iteration;
-    gout->k = gin->k;
-    gout->n_hist = gin->n_hist;
-    gout->converged = gin->converged;
-    gout->done = done_in;
-    gout->valid = gin->valid;
-    gout->outlier = gin->outlier;
-    gout->invalid = gin->invalid;
-    if (done_in) {
-      const bool to_host = !PIXEL && g.host_full && g.host_out != nullptr && blockIdx.y == 0;
-      for (int w = 0; w < SUMA_ACC_WORDS; ++w) gout->acc[w] = gin->acc[w];
-      for (int w = 0; w < 36; ++w) { /* information() of a chain that has converged */
-        const double v = gin->JtJ[w];
-        gout->JtJ[w] = v;
-        if (to_host) g.host_out->JtJ[w] = v;
-      }
-      for (int w = 0; w < 6; ++w) {
-        const double v = gin->Jtr[w];
-        gout->Jtr[w] = v;
-        if (to_host) g.host_out->Jtr[w] = v;
-      }
+  } else if (blockIdx.x == 0 && threadIdx.x < 64 && !g.init) {
+    /* Nothing to consume: carry the state over to the other buffer (the buffers alternate with the launch parity).
+     * Round 6: the WHOLE record, one 8-byte word per lane and trip, all loads in flight together.  Round 5 had thread 0
+     * copy it field by field -- ~90 dependent cold round trips, 11.5 us: a launch that found its chain CONVERGED took
+     * longer than one that worked (9.2 us), and a minimisation in the reference's own mode (stopping tests on, 33
+     * iterations at most: LieGaussNewton.cpp:23-33, default.xml:16) enqueues two dozen of them
+     * (profiles/r06_gn_done_launch.txt).  The word that holds `pending` is left to thread 0, which stores that field on
+     * every path below; acc / JtJ / Jtr of a chain that is not done are don't-cares (the next consume step rewrites
+     * them) and travel along. */
+    static_assert(sizeof(GnState) % 8 == 0 && offsetof(GnState, pending) % 8 == 0, "GnState is carried as 8-byte words");
+    const unsigned long long* __restrict__ src = reinterpret_cast<const unsigned long long*>(gin);
+    unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(gout);
+#pragma unroll
+    for (int w0 = 0; w0 < (int)(sizeof(GnState) / 8); w0 += 64) {
+      const int w = w0 + (int)threadIdx.x;
+      if (w < (int)(sizeof(GnState) / 8) && w != (int)(offsetof(GnState, pending) / 8)) dst[w] = src[w];
+    }
+    if (done_in && !PIXEL && g.host_full && g.host_out != nullptr && blockIdx.y == 0 && threadIdx.x < 42) {
+      /* information() of a chain that has converged */
+      if (threadIdx.x < 36)
+        g.host_out->JtJ[threadIdx.x] = gin->JtJ[threadIdx.x];
+      else
+        g.host_out->Jtr[threadIdx.x - 36] = gin->Jtr[threadIdx.x - 36];
     }
   }
+  /* the record the closing report below reads this launch's statistics from: thread 0's own stores where it consumed
+   * or initialised, the previous launch's record where the state was only carried (other lanes wrote the copy) */
+  const GnState* __restrict__ rs = (pending || g.init) ? gout : gin;
 
   if (!PIXEL || (done && !g.eval_only) || (g.eval_only && pending)) {
     if (writer) {
@@ -675,15 +676,15 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
       if (!PIXEL && g.host_out != nullptr && blockIdx.y == 0) {
         HostResult* __restrict__ h = g.host_out;
         for (int i = 0; i < 16; ++i) h->Tk[i] = Tk[i];
-        h->F = gout->F; /* own earlier stores (every branch above leaves gout complete) */
-        h->F_inlier = gout->F_inlier;
-        h->valid = gout->valid;
-        h->outlier = gout->outlier;
-        h->invalid = gout->invalid;
-        h->k = gout->k;
-        h->converged = gout->converged;
-        h->iteration = gout->iteration;
-        h->n_hist = gout->n_hist;
+        h->F = rs->F; /* own earlier stores, or the carried record's source */
+        h->F_inlier = rs->F_inlier;
+        h->valid = rs->valid;
+        h->outlier = rs->outlier;
+        h->invalid = rs->invalid;
+        h->k = rs->k;
+        h->converged = rs->converged;
+        h->iteration = rs->iteration;
+        h->n_hist = rs->n_hist;
         /* read here, behind the solve: requested up front with the prologue's loads the 64 bytes made the launch
          * 1.4 us LONGER (rocprofv3: 9.33 against 7.90 us; profiles/r04_late_experiments.txt) */
         h->ds = *g.ds;
