@@ -67,36 +67,51 @@ __device__ __forceinline__ void lookback_publish(unsigned long long* __restrict_
  * Every spin is bounded (SUMA_SPIN_LIMIT polls, seconds of wall time): a protocol error must surface
  * as an error code (DevState.overflow bit 3), never as a hung GPU. */
 #define SUMA_SPIN_LIMIT (1u << 26)
+#ifndef LB_BATCH
+#define LB_BATCH 4 /* group words a lane requests before it looks at the first one */
+#endif
 template <bool PAIR>
 __device__ Pair lookback_collect2(unsigned long long* __restrict__ status, unsigned long long* __restrict__ group,
                                   uint32_t tile, uint32_t epoch, int lane, uint32_t* __restrict__ fault) {
   const uint32_t g = tile >> 6;
   uint32_t sum = 0, sumx = 0;
   bool timed_out = false;
+  /* Round 6: every word this wave needs is REQUESTED before the first one is looked at -- the status word of the lane's
+   * earlier tile of the own group first, then the group accumulators LB_BATCH at a time.  Round 5 walked them one load,
+   * one check at a time: two dependent memory-side round trips per tile at the 1 M map (groups, then own group), and
+   * ceil(groups / 64) + 1 of them at 50 M surfels (763 groups: twelve).  A word that is not complete yet is polled as
+   * before, lane by lane; the values added are the same, so is the result. */
+  const uint32_t j = tile & 63u;
+  const bool own = (uint32_t)lane < j;
+  unsigned long long ws = 0;
+  if (own) ws = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   /* complete groups before mine: every group before g holds exactly 64 tiles */
-  for (uint32_t gi = lane; gi < g; gi += 64) {
-    unsigned long long w;
-    uint32_t spins = 0;
-    for (;;) {
-      w = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(w >> 56) == 64u || ++spins >= SUMA_SPIN_LIMIT) break;
+  for (uint32_t base = 0; base < g; base += 64u * LB_BATCH) {
+    unsigned long long w[LB_BATCH];
+#pragma unroll
+    for (int q = 0; q < LB_BATCH; ++q) {
+      const uint32_t gi = base + (uint32_t)q * 64u + (uint32_t)lane;
+      w[q] = gi < g ? __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (64ull << 56);
     }
-    timed_out |= (spins >= SUMA_SPIN_LIMIT);
-    sum += (uint32_t)(w & 0xffffffffull);
-    if (PAIR) sumx += (uint32_t)(w >> 32) & 0xffffffu;
+#pragma unroll
+    for (int q = 0; q < LB_BATCH; ++q) {
+      const uint32_t gi = base + (uint32_t)q * 64u + (uint32_t)lane;
+      uint32_t spins = 0;
+      while ((uint32_t)(w[q] >> 56) != 64u && ++spins < SUMA_SPIN_LIMIT)
+        w[q] = __hip_atomic_load(&group[gi], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      timed_out |= (spins >= SUMA_SPIN_LIMIT);
+      sum += (uint32_t)(w[q] & 0xffffffffull); /* a lane beyond the last group adds the zero it was given */
+      if (PAIR) sumx += (uint32_t)(w[q] >> 32) & 0xffffffu;
+    }
   }
   /* earlier tiles of my own group */
-  const uint32_t j = tile & 63u;
-  if ((uint32_t)lane < j) {
-    unsigned long long w;
+  if (own) {
     uint32_t spins = 0;
-    for (;;) {
-      w = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!((uint32_t)(w >> 34) != (epoch & 0x3fffffffu) || ((w >> 32) & 3ull) == 0) || ++spins >= SUMA_SPIN_LIMIT) break;
-    }
+    while (((uint32_t)(ws >> 34) != (epoch & 0x3fffffffu) || ((ws >> 32) & 3ull) == 0) && ++spins < SUMA_SPIN_LIMIT)
+      ws = __hip_atomic_load(&status[(g << 6) + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     timed_out |= (spins >= SUMA_SPIN_LIMIT);
-    sum += (uint32_t)(w & 0xffffull);
-    if (PAIR) sumx += (uint32_t)(w >> 16) & 0xffffu;
+    sum += (uint32_t)(ws & 0xffffull);
+    if (PAIR) sumx += (uint32_t)(ws >> 16) & 0xffffu;
   }
   if (timed_out) {
     atomicOr(fault, 8u);
