@@ -97,6 +97,9 @@ __device__ __forceinline__ long long fix_bits(float term, double scale, double m
   double d = __builtin_fma((double)term, scale, magic);
   return __double_as_longlong(d);
 }
+/* lane-trips of one pixel phase: the wave that starts at pixel 64 q runs a trip for every q with 64 q < P, all of its 64
+ * lanes taking part (a lane beyond the image hands in zeros) -- whatever the grid is */
+__device__ __forceinline__ unsigned long long lane_trips(uint32_t P) { return 64ull * ((P + 63u) / 64u); }
 __device__ __forceinline__ void fix_consts(double* scale, double* magic) {
   double sc = SUMA_ACC_SCALE, mg = MAGIC_D;
   asm volatile("" : "+v"(sc), "+v"(mg)); /* opaque: keeps both in VGPR pairs */
@@ -478,10 +481,10 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
       long long sum = (rec[0] + rec[1]) + (rec[2] + rec[3]);
       GN_STAMP(1); /* state words + records have arrived */
       sum += shfl_xor_ll(sum, 32);
-      const long long n_valid = readlane_ll(sum, 29), n_outlier = readlane_ll(sum, 30), n_inlier = n_valid - n_outlier;
       const int w = threadIdx.x & 31;
-      if (w < 27 || w == 28) sum -= n_inlier * MAGIC_BITS;
-      if (w == 27) sum -= n_valid * MAGIC_BITS;
+      /* every lane-trip of the pixel phase has added the magic number to each of the 29 fixed-point words (terms that
+       * do not contribute are formed from a zero weight, not selected away: see the pixel phase) */
+      if (w < 29) sum = (long long)((unsigned long long)sum - (unsigned long long)lane_trips(a.P) * (unsigned long long)MAGIC_BITS);
       if (threadIdx.x < SUMA_ACC_WORDS) {
         s_wave[0][w] = sum;
         s_val[w] = (double)sum * (1.0 / SUMA_ACC_SCALE);
@@ -803,6 +806,14 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
       J[5] = cp.z;
       wgt = weight;
     }
+    /* Round 6: a term that does not contribute is formed from a ZERO WEIGHT instead of being selected away behind its
+     * conversion -- fix_bits(0) is the magic number itself, so every lane-trip adds exactly one magic number to each of
+     * the 29 fixed-point words and the consume step removes lane_trips(P) of them (round 5: 29 64-bit selects per pixel
+     * and a bias of n_inlier / n_valid magic numbers).  The sums are the same integers; ~55 VALU instructions per
+     * pixel fewer in a phase that is issue bound at two waves per SIMD.  J is finite for every pair (both texels valid),
+     * so 0 * J is a zero. */
+    const bool in = pair && is_inlier;
+    const float wgt_in = in ? wgt : 0.0f, wr_in = in ? wr : 0.0f, wr2_in = in ? wr2 : 0.0f;
     /* words 0..15: the first 16 entries of the upper triangle of J^T W J (row-major: (0,0)..(0,5), (1,1)..(1,5),
      * (2,2)..(2,5), (3,3)) */
     {
@@ -810,10 +821,10 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
       int k = 0;
 #pragma unroll
       for (int i = 0; i < 6; ++i) {
-        const float wJi = wgt * J[i];
+        const float wJi = wgt_in * J[i];
 #pragma unroll
         for (int j = i; j < 6; ++j) {
-          if (k < 16) h[k] = (pair && is_inlier) ? fix_bits(wJi * J[j], fx_scale, fx_magic) : 0ll;
+          if (k < 16) h[k] = fix_bits(wJi * J[j], fx_scale, fx_magic);
           ++k;
         }
       }
@@ -823,19 +834,18 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
      * inliers, the three counters */
     {
       long long h[16];
-      const bool in = pair && is_inlier;
-      h[0] = in ? fix_bits((wgt * J[3]) * J[4], fx_scale, fx_magic) : 0ll;
-      h[1] = in ? fix_bits((wgt * J[3]) * J[5], fx_scale, fx_magic) : 0ll;
-      h[2] = in ? fix_bits((wgt * J[4]) * J[4], fx_scale, fx_magic) : 0ll;
-      h[3] = in ? fix_bits((wgt * J[4]) * J[5], fx_scale, fx_magic) : 0ll;
-      h[4] = in ? fix_bits((wgt * J[5]) * J[5], fx_scale, fx_magic) : 0ll;
+      h[0] = fix_bits((wgt_in * J[3]) * J[4], fx_scale, fx_magic);
+      h[1] = fix_bits((wgt_in * J[3]) * J[5], fx_scale, fx_magic);
+      h[2] = fix_bits((wgt_in * J[4]) * J[4], fx_scale, fx_magic);
+      h[3] = fix_bits((wgt_in * J[4]) * J[5], fx_scale, fx_magic);
+      h[4] = fix_bits((wgt_in * J[5]) * J[5], fx_scale, fx_magic);
 #pragma unroll
-      for (int i = 0; i < 6; ++i) h[5 + i] = in ? fix_bits(wr * J[i], fx_scale, fx_magic) : 0ll;
-      h[11] = pair ? fix_bits(wr2, fx_scale, fx_magic) : 0ll; /* word 27 */
-      h[12] = in ? fix_bits(wr2, fx_scale, fx_magic) : 0ll;   /* word 28 */
-      h[13] = pair ? 1ll : 0ll;                               /* word 29: valid */
-      h[14] = (pair && !is_inlier) ? 1ll : 0ll;               /* word 30: outlier */
-      h[15] = (valid_px && !pair) ? 1ll : 0ll;                /* word 31: invalid */
+      for (int i = 0; i < 6; ++i) h[5 + i] = fix_bits(wr_in * J[i], fx_scale, fx_magic);
+      h[11] = fix_bits(wr2, fx_scale, fx_magic);    /* word 27: F over all pairs (wr2 is 0 without a pair) */
+      h[12] = fix_bits(wr2_in, fx_scale, fx_magic); /* word 28: F over the inliers */
+      h[13] = pair ? 1ll : 0ll;                     /* word 29: valid */
+      h[14] = (pair && !is_inlier) ? 1ll : 0ll;     /* word 30: outlier */
+      h[15] = (valid_px && !pair) ? 1ll : 0ll;      /* word 31: invalid */
       totB += wave_reduce16(h, lane);
     }
   }
@@ -874,11 +884,11 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
         long long s = 0;
 #pragma unroll
         for (int q = 0; q < ICP_RECORDS; ++q) s += s_tot[q][threadIdx.x];
-        const long long n_valid = readlane_ll(s, 29), n_outlier = readlane_ll(s, 30), n_inlier = n_valid - n_outlier;
+        const long long n_valid = readlane_ll(s, 29), n_outlier = readlane_ll(s, 30);
         const long long n_invalid = readlane_ll(s, 31);
         const int w = threadIdx.x;
-        if (w < 27 || w == 28) s -= n_inlier * MAGIC_BITS; /* the same bias rule as the consume step above */
-        if (w == 27) s -= n_valid * MAGIC_BITS;
+        /* the same bias rule as the consume step above */
+        if (w < 29) s = (long long)((unsigned long long)s - (unsigned long long)lane_trips(a.P) * (unsigned long long)MAGIC_BITS);
         const double v = (double)s * (1.0 / SUMA_ACC_SCALE);
         HostResult* __restrict__ h = g.fused_report;
         if (w == 27) h->F = v;
