@@ -10,7 +10,8 @@ TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 export SUMA_SCAN_CACHE=/tmp/suma_scans
 B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0"
-timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -2 > "$O/pytest_gpu.txt"
+# the driver's exact command first (round-5 review item 3): -x, so that a failure anywhere shows as what the driver would record
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -4 > "$O/pytest_gpu.txt"
 timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
 timeout 300 python bench.py --steps 20 2>"$O/bench_driver_shape.err" | tail -1 > "$O/bench_driver_shape_steps20.json"
 timeout 900 $B --no-host-vectors --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
@@ -28,6 +29,9 @@ timeout 300 python tools/multi_seq.py 4 60 2>/dev/null | tail -1 > "$O/multi_seq
 SUMA_BENCH_FORCE_DEVICE=0 timeout 300 python bench.py --gpus 2 --backend gloo --steps 20 --cpu-scans 0 --adapter-scans 0 --no-kernel-events 2>/dev/null | tail -1 > "$O/bench_gpus2_self_launched_gloo.json"
 timeout 300 python tools/phase_timeline.py 250 30 2>&1 | tail -19 > "$O/phase_timeline.txt"
 timeout 300 python tools/gn_timeline.py 2>&1 | tail -14 > "$O/gn_timeline.txt"
+# round 6: the loop-closure verification batched / serial / one guess, and the host-vector entry against the CPUs granted
+timeout 300 python tools/loop_closure_timing.py 2048 150 33 > "$O/loop_closure_timing.json" 2>/dev/null
+timeout 600 bash tools/host_entry_cpus.sh "$O/host_entry_cpus.jsonl" > /dev/null 2>&1
 # LAST, so that it can never trail the sources again (round-4 review): BASELINE configs[1] verbatim, all 4541 scans of the
 # shipped build against the oracle's recorded trace -- the JSON names the kernel sources (kernel_source_sha) it ran on
 timeout 900 python tools/long_parity.py --check tests/golden/long_trace_4541.npz --out "$O/long_parity_4541_scans.json" 2>"$O/long_parity.err" | tail -1 | cut -c1-300
