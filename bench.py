@@ -556,16 +556,20 @@ def main():
                 for _ in range(reps):
                     r = core.loop_closure_verify(ctx, cur, prior, guesses, prior, ctv, *gates, serial=serial)
                 ctx.synchronize()
-                return 1e6 * (time.perf_counter() - t) / reps, [bool(x["passed"]) for x in r]
+                return 1e6 * (time.perf_counter() - t) / reps, [bool(x["passed"]) for x in r], [int(x["after_minimize"]["iterations"]) for x in r]
 
             loop_closure = {"n_init": 3, "repetitions": reps, "map_surfels": pipe.map.size(), "unit": "us per verification"}
             for name, gates in (("reference_gates", (0.2, 0.85)), ("no_guess_passes", (2.0, 0.85))):
-                b, pb = clock(inits, gates, False)
-                sq, ps = clock(inits, gates, True)
-                one, _ = clock(inits[:1], gates, False)
+                b, pb, it = clock(inits, gates, False)
+                sq, ps, _ = clock(inits, gates, True)
+                one, _, _ = clock(inits[:1], gates, False)
                 assert pb == ps
+                # gn_iterations: steps each guess's chain took before the stopping tests fired (max iterations = the chain
+                # never converged and all its launches worked: then three chains side by side cost what the batched pixel
+                # phase costs, ~2 x one chain; chains that converge early are where batching pays: tools/loop_closure_timing.py)
                 loop_closure[name] = {"batched": round(b, 1), "serial": round(sq, 1), "one_guess": round(one, 1),
-                                      "batched_over_one_guess": round(b / one, 3), "passed": pb}
+                                      "batched_over_one_guess": round(b / one, 3), "serial_over_batched": round(sq / b, 3),
+                                      "passed": pb, "gn_iterations": it, "max_iterations": int(p.max_iterations)}
         except Exception as e:  # noqa: BLE001 -- an extra must never cost the bench line
             print(f"loop_closure leg not taken: {e!r}", file=sys.stderr)
     if seq is None:  # synthetic trajectory: known ground truth
