@@ -472,6 +472,9 @@ def main():
     ctx.synchronize()
     own = time.perf_counter() - t0  # this rank's scans alone: everything behind it is waiting for the slowest rank
     poses = gather_pose(pipe.getCurrentPose()) if world > 1 else None
+    if native is not None:  # the one data-path collective of the run is done: every rank destroys its communicator here
+        native.close()
+        native = None
     barrier()
     elapsed = time.perf_counter() - t0
     per_rank = None

@@ -746,6 +746,9 @@ def test_batched_loop_closure_verification_equals_the_sequential_form(hip, oracl
         g = [O, Rz, half, far]
         cases = [(order, gates) for order in ([0, 1, 2], [1, 2, 0], [3, 1, 0], [3, 3, 0], [0], [1, 3, 2, 0, 2, 1, 0])
                  for gates in (ref_gates, nobody, everybody)]
+        # more guesses than one batched launch holds (SUMA_MAX_HYP = 64): the rounds continue behind the first 64, with
+        # the iteration counter that the chains in front have moved
+        cases += [([3, 1, 2] * 23 + [0], nobody), ([3, 1] * 33 + [0, 2, 0], ref_gates)]
     else:
         # "until convergence" has no iteration cap, and on this four-scan map many chains end in a limit cycle (300
         # iterations without meeting LieGaussNewton.cpp:64-66 -- the reference would iterate for ever as well): only
