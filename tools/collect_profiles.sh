@@ -19,5 +19,5 @@ else
   python tools/sq_summary.py "$O"/pmc_sq1/*counter_collection.csv "$O"/pmc_sq2/*counter_collection.csv "$O"/pmc_sq3/*counter_collection.csv > "${P}_sq_summary.txt"
 fi
 cp "$O/stress.json" "${P}_stress_50M_surfels_128x4096.json"
-for f in long_parity_4541_scans.json bench_driver_shape_steps20.json bench_full_sequence_4541.json bench_hypotheses.json bench_sequences11.json adapter_path_300_scans.json ingest.json multi_seq.txt bench_gpus2_self_launched_gloo.json phase_timeline.txt gn_timeline.txt loop_closure_timing.json host_entry_cpus.jsonl; do [ -s "$O/$f" ] && cp "$O/$f" "${P}_$f"; done
+for f in long_parity_4541_scans.json bench_driver_shape_steps20.json bench_full_sequence_4541.json bench_hypotheses.json bench_sequences11.json adapter_path_300_scans.json ingest.json multi_seq.txt bench_gpus2_self_launched_gloo.json phase_timeline.txt gn_timeline.txt loop_closure_timing.json host_entry_cpus.jsonl scan_timeline_gaps.txt; do [ -s "$O/$f" ] && cp "$O/$f" "${P}_$f"; done
 ls -la profiles | tail -24

@@ -11,6 +11,7 @@ bash tools/pmc_refresh.sh "$TAG" > "$O/pmc_refresh.log" 2>&1
 f1() { find "$O/$1" -name "$2" | head -1; }
 python tools/rocprof_summary.py "$(f1 prof '*kernel_trace.csv')" > "$O/kernel_trace_summary.txt" 2>&1
 cp "$(f1 prof '*kernel_stats.csv')" "$O/rocprofv3_kernel_stats.csv"
+python tools/trace_gaps.py "$(f1 prof '*kernel_trace.csv')" 340 360 > "$O/scan_timeline_gaps.txt" 2>&1
 python tools/make_hbm_traffic.py "$(f1 pmc_fetch '*counter_collection.csv')" "$(f1 pmc_write '*counter_collection.csv')" 2048 64 "$O/hbm_traffic.json" > "$O/hbm_traffic_pmc.txt" 2>&1
 python tools/sq_summary.py "$(f1 pmc_sq1 '*counter_collection.csv')" "$(f1 pmc_sq2 '*counter_collection.csv')" "$(f1 pmc_sq3 '*counter_collection.csv')" > "$O/sq_summary.txt" 2>&1
 rm -rf "$O/prof" "$O/pmc_fetch" "$O/pmc_write" "$O/pmc_sq1" "$O/pmc_sq2" "$O/pmc_sq3"
