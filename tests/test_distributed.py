@@ -187,6 +187,46 @@ def _run(mode):
     return sorted(out, key=lambda o: o[0])
 
 
+def _native_gather_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from semantic_suma_amd.distributed import NativeGather, gather_poses
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        class NoCtx:  # a machine without a GPU has no suma_ctx: the bootstrap must say so before anybody needs one
+            h = None
+        ng = NativeGather(NoCtx(), device=torch.device("cpu"))
+        # what bench.py does with the answer: every rank takes the SAME branch
+        got = gather_poses(np.full((4, 4), float(rank))) if not ng.ok else None
+        q.put((rank, ng.ok, ng.error, None if got is None else got[:, 0, 0].tolist()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_gather_bootstrap_fails_together_without_a_gpu():
+    """`bench.py --gpus N` gathers its poses through libsuma_hip_dist.so (suma_gather_poses), bootstrapped over the
+    launcher's process group (semantic_suma_amd.distributed.NativeGather).  N > 1 ranks on RCCL cannot run here -- but
+    the protocol around it can: two gloo ranks on a machine without a GPU.  The library loads, rank 0's RCCL id reaches
+    rank 1, ncclCommInitRank fails on both (no device), and BOTH ranks leave the constructor with ok = False and a reason --
+    nobody hangs in a collective the other side never enters -- and fall back to the same torch.distributed gather."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_native_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert [o[0] for o in out] == [0, 1]
+    assert all(o[1] is False and o[2] for o in out), out   # both refused, both know why
+    assert all(o[3] == [0.0, 1.0] for o in out), out        # and the fallback gather ran on both
+
+
 def test_lpt_assignment():
     from semantic_suma_amd.distributed import lpt_assign
     kitti = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # odometry 00-10 scan counts
