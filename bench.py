@@ -312,6 +312,8 @@ def main():
                     help="least number of scans of the host-vector entry's sample (it is max(--steps, this))")
     ap.add_argument("--no-host-vectors", action="store_true",
                     help="skip the host-vector entry (suma_pipeline_process_scan from pageable arrays) timed behind the contract's region")
+    ap.add_argument("--no-reference-mode", action="store_true",
+                    help="skip the extra stretch in the reference's own Gauss-Newton mode (stopping tests, max iterations 33)")
     ap.add_argument("--no-loop-closure", action="store_true", help="skip the loop-closure verification timing (batched vs serial)")
     ap.add_argument("--mode", default="single", choices=["single", "hypotheses", "sequences11", "adapter"],
                     help="single: BASELINE configs[1] (the bench contract); hypotheses: configs[2], 8 ICP hypotheses per scan "
@@ -409,7 +411,10 @@ def main():
     # 3 - 6 ms twice (profiles/r05_host_vector_calls.txt); a caller that feeds host vectors scan after scan -- the thing
     # this key measures -- never has that gap
     HVW = 3 if HV else 0
-    total = n_before + K + HVW + HV + E
+    # ... and RM scans in the reference's OWN Gauss-Newton mode at the very end: stopping tests on, `max iterations` of the
+    # parameter block (default.xml: 33) -- LieGaussNewton.cpp:23-33, what an unchanged caller gets with fixed_iterations = 0
+    RM = 0 if args.no_reference_mode else 40
+    total = n_before + K + HVW + HV + E + RM
     seq = None
     if kitti_dir:
         from semantic_suma_amd import kitti
@@ -575,6 +580,24 @@ def main():
                                       "passed": pb, "gn_iterations": it, "max_iterations": int(p.max_iterations)}
         except Exception as e:  # noqa: BLE001 -- an extra must never cost the bench line
             print(f"loop_closure leg not taken: {e!r}", file=sys.stderr)
+    reference_mode = None
+    if RM:
+        first = n_before + K + HVW + HV + E
+        job = pipe.prepareScans([scans[k][:4] for k in range(first, first + RM)], True)
+        pipe.processScanDevice(*scans[first][:4], fixed_iterations=0)  # untimed: the mode's first scan
+        job = pipe.prepareScans([scans[k][:4] for k in range(first + 1, first + RM)], True)
+        barrier()
+        tr = time.perf_counter()
+        assert pipe.runScans(job, True, fixed_iterations=0) == RM - 1
+        ctx.synchronize()
+        tr = time.perf_counter() - tr
+        st = pipe.minimizeStats()
+        reference_mode = {"value": (RM - 1) / tr, "unit": "scans/s", "scans": RM - 1, "max_iterations": int(p.max_iterations),
+                          "stopping_threshold": float(p.stopping_threshold), "delta": float(p.delta),
+                          "last_scan_gn_iterations": int(st.iterations), "last_scan_converged": bool(st.converged),
+                          "map_surfels": pipe.map.size(),
+                          "what": "the same pipeline with fixed_iterations = 0: LieGaussNewton's stopping tests decide "
+                                  "(LieGaussNewton.cpp:23-33, 64-66), at most `max iterations` steps; NOT the headline"}
     if seq is None:  # synthetic trajectory: known ground truth
         gt = np.linalg.inv(synth.trajectory_pose(k0)) @ synth.trajectory_pose(k0 + n_before + K - 1)  # pose taken before the host-vector stretch
         drift = float(np.linalg.norm((np.linalg.inv(pose) @ gt)[:3, 3]))
@@ -613,6 +636,8 @@ def main():
         out["host_vector_entry"] = host_vectors
     if loop_closure is not None:
         out["loop_closure_verify"] = loop_closure
+    if reference_mode is not None:
+        out["reference_mode"] = reference_mode
 
     def derive(ks):
         for k in ks:

@@ -994,6 +994,12 @@ class SurfelMapping:
         self.L.suma_pipeline_last_stats(self.h, C.byref(st))
         return st
 
+    def minimizeStats(self) -> IcpStats:
+        """statistics of the scan's minimisation itself (iterations, converged: suma_pipeline_minimize_stats)"""
+        st = IcpStats()
+        self.L.suma_pipeline_minimize_stats(self.h, C.byref(st))
+        return st
+
     def timestamp(self) -> int:
         return self.L.suma_pipeline_timestamp(self.h)
 
