@@ -118,3 +118,47 @@ def test_gl_interop_recipe_on_the_gpu_box(hip, tmp_path):
                            "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "without a GL context: hipError" in out.stdout, out.stdout + out.stderr
+
+
+def test_bench_reads_a_kitti_format_directory(hip, tmp_path):
+    """SUMA_KITTI_DIR (KITTIReader.cpp:136-203): bench.py's KITTI branch on a `sequences/00` directory in
+    the dataset's own formats -- velodyne/*.bin (N x 4 float32: x, y, z, remission), labels/*.label (uint32, class id in
+    the lower 16 bits), calib.txt.  No KITTI scan exists on either machine, so the files are the synthetic sequence
+    written in those formats: what is exercised is the reader path end to end (the remission column dropped, labels
+    remapped as RangeNet++ reports them, label / prob offsets of quirk B-1 switched off), the line says data = kitti,
+    and the same files through the Python mirror give the pose the in-memory scans give."""
+    import json
+    import sys
+    from semantic_suma_amd import kitti
+    W, N = 900, 30
+    root = tmp_path / "sequences" / "00"
+    (root / "velodyne").mkdir(parents=True)
+    (root / "labels").mkdir()
+    mem = []
+    for k in range(N):
+        pts, lab, prob, _ = get_scan(k, W, True)
+        raw = pts.copy()
+        raw[:, 3] = 0.37  # remission: the reader must drop it
+        raw.astype("<f4").tofile(str(root / "velodyne" / f"{k:06d}.bin"))
+        (lab.astype("<u4") | np.uint32(7 << 16)).astype("<u4").tofile(str(root / "labels" / f"{k:06d}.label"))
+        mem.append((pts, lab))
+    (root / "calib.txt").write_text("Tr: 0 -1 0 0 0 0 -1 0 1 0 0 0\n")
+    env = dict(os.environ, SUMA_KITTI_DIR=str(root))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--width", str(W), "--steps", "5", "--warmup", "2",
+                          "--preroll", "12", "--cpu-scans", "0", "--adapter-scans", "0", "--no-kernel-events",
+                          "--host-vector-scans", "5", "--no-loop-closure", "--no-reference-mode"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["data"] == "kitti" and d["value"] > 100 and d["config"]["points_per_scan"] > 10000
+    # the same files through the reader and the Python mirror against the in-memory scans they were written from
+    seq = kitti.Sequence(str(root))
+    assert len(seq) == N
+    p = params_with_size(W, label_offset=0, prob_offset=0)
+    a, b = hip.SurfelMapping(p), hip.SurfelMapping(p)
+    for k in range(6):
+        pts, lab, prob = seq[k]
+        assert np.array_equal(pts, mem[k][0]) and np.array_equal(lab, mem[k][1]) and (prob == 1).all()
+        a.processScan(pts, lab, prob, fixed_iterations=6)
+        b.processScan(mem[k][0], mem[k][1], np.ones_like(prob), fixed_iterations=6)
+    assert np.array_equal(a.getCurrentPose(), b.getCurrentPose()) and a.getCurrentPose()[0, 3] > 3.0
