@@ -177,6 +177,9 @@ int suma_map_download_index_map(suma_ctx* ctx, uint32_t* host);      /* P, surfe
 int suma_map_download_radius_conf(suma_ctx* ctx, suma_float4* host); /* P */
 int suma_map_download_integrated(suma_ctx* ctx, uint8_t* host);      /* P */
 int suma_map_counts(suma_ctx* ctx, uint32_t* n_updated, uint32_t* n_new, uint32_t* n_cached, int32_t origin_ij[2]);
+/* SurfelMap::poses_ (SurfelMap.h:205-208): the pose table, entries 0 .. timestamp - 1 (16 floats each, column-major; after
+ * suma_map_update_poses the optimised ones).  *n = entries in the table; min(*n, capacity) are copied. */
+int suma_map_download_poses(suma_ctx* ctx, float* host, uint32_t capacity, uint32_t* n);
 /* the submap cache in HBM (the reference pages tiles to host vectors, SurfelMap.h:186, SurfelMap.cpp:733-734): surfels
  * allocated from the arena (live tiles + the blocks that re-extracted tiles left behind), its capacity
  * (suma_params.cache_surfels), and how often it has been compacted -- when it runs full the live tiles are copied into

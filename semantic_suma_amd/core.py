@@ -151,6 +151,7 @@ def lib():
     L.suma_map_upload.argtypes = [vp, vp, u32, u32]
     L.suma_map_download_index_map.argtypes = [vp, vp]
     L.suma_map_download_radius_conf.argtypes = [vp, vp]
+    L.suma_map_download_poses.argtypes = [vp, vp, u32, C.POINTER(u32)]
     L.suma_map_download_integrated.argtypes = [vp, vp]
     L.suma_map_counts.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32), vp]
     L.suma_map_cache_stats.argtypes = [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
@@ -632,6 +633,15 @@ class SurfelMap:
         out = np.zeros((p.data_height, p.data_width), dtype=np.uint32)
         self.ctx.check(self.ctx.L.suma_map_download_index_map(self.ctx.h, _ptr(out)))
         return out
+
+    def poses(self):
+        """the pose table (SurfelMap::poses_): [timestamp, 4, 4] float32, one pose per integrated scan"""
+        t = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_timestamp(self.ctx.h, C.byref(t)))
+        out = np.zeros((max(t.value, 1), 16), dtype=np.float32)
+        n = C.c_uint32(0)
+        self.ctx.check(self.ctx.L.suma_map_download_poses(self.ctx.h, _ptr(out), t.value, C.byref(n)), "suma_map_download_poses")
+        return out[:min(n.value, t.value)].reshape(-1, 4, 4).transpose(0, 2, 1).copy()
 
     def radius_conf(self):
         p = self.ctx.params

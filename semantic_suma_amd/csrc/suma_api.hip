@@ -1367,6 +1367,19 @@ extern "C" int suma_map_download_radius_conf(suma_ctx* c, suma_float4* host) {
   CK(hipStreamSynchronize(c->stream));
   return SUMA_OK;
 }
+/* SurfelMap::poses_ (SurfelMap.h:205-208): the pose table the surfels refer to by creation stamp, entries 0 .. timestamp - 1,
+ * column-major floats -- the trajectory as the map holds it (after updatePoses: the optimised one) */
+extern "C" int suma_map_download_poses(suma_ctx* c, float* host, uint32_t capacity, uint32_t* n) {
+  if (!c || !n || (capacity && !host)) return SUMA_ERR_INVALID;
+  *n = c->timestamp;
+  const uint32_t m = c->timestamp < capacity ? c->timestamp : capacity;
+  if (m) {
+    CK(hipMemcpyAsync(host, c->poses, (size_t)m * 16 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    CK(hipStreamSynchronize(c->stream));
+    host_synced(c);
+  }
+  return SUMA_OK;
+}
 extern "C" int suma_map_download_integrated(suma_ctx* c, uint8_t* host) {
   if (!c || !host) return SUMA_ERR_INVALID;
   CK(hipMemcpyAsync(host, c->integrated, c->P, hipMemcpyDeviceToHost, c->stream));

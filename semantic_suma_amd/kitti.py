@@ -104,3 +104,53 @@ class Sequence:
             labels = np.zeros(pts.shape[0], np.float32)
             probs = np.zeros(pts.shape[0], np.float32)
         return pts, labels, probs
+
+
+# ---- KITTI odometry devkit error metric (src/util/kitti_utils.cpp:108-191: trajectoryDistances,
+#      lastFrameFromSegmentLength, rotationError, translationError, calcSequenceErrors) ----
+SEGMENT_LENGTHS = (100, 200, 300, 400, 500, 600, 700, 800)
+
+
+def odometry_errors(poses_gt, poses_est, lengths=SEGMENT_LENGTHS, step: int = 10):
+    """Relative pose error over all sub-sequences of the devkit's lengths, every `step` frames (kitti_utils.cpp:153-191):
+    returns dict(t_err = mean translation error per metre, r_err = mean rotation error in rad per metre, segments = number
+    of (start, length) pairs that fit, per_length = {length: (t_err, r_err, count)}).  Distances are measured along the
+    ground truth; a pair contributes only if the trajectory is long enough.  None if no segment fits."""
+    G = np.asarray(poses_gt, dtype=np.float64).reshape(-1, 4, 4)
+    E = np.asarray(poses_est, dtype=np.float64).reshape(-1, 4, 4)
+    n = min(len(G), len(E))
+    if n < 2:
+        return None
+    G, E = G[:n], E[:n]
+    dist = np.concatenate([[0.0], np.cumsum(np.linalg.norm(G[1:, :3, 3] - G[:-1, :3, 3], axis=1))])
+    per = {}
+    for first in range(0, n, step):
+        for length in lengths:
+            later = np.nonzero(dist[first:] > dist[first] + length)[0]  # lastFrameFromSegmentLength
+            if later.size == 0:
+                continue
+            last = first + int(later[0])
+            d_gt = np.linalg.inv(G[first]) @ G[last]
+            d_est = np.linalg.inv(E[first]) @ E[last]
+            err = np.linalg.inv(d_est) @ d_gt
+            r = float(np.arccos(max(-1.0, min(1.0, 0.5 * (np.trace(err[:3, :3]) - 1.0)))))
+            t = float(np.linalg.norm(err[:3, 3]))
+            per.setdefault(length, []).append((t / length, r / length))
+    if not per:
+        return None
+    allv = np.array([v for vs in per.values() for v in vs])
+    return dict(t_err=float(allv[:, 0].mean()), r_err=float(allv[:, 1].mean()), segments=int(len(allv)),
+                per_length={int(k): (float(np.mean([v[0] for v in vs])), float(np.mean([v[1] for v in vs])), len(vs))
+                            for k, vs in sorted(per.items())})
+
+
+def read_poses(path: str, Tr: np.ndarray = None) -> np.ndarray:
+    """poses/XX.txt of the odometry benchmark: 12 values per line, camera frame; with the calibration's Tr they are
+    brought into the velodyne frame (the inverse of poses_to_camera_frame)"""
+    rows = np.loadtxt(path).reshape(-1, 12)
+    P = np.tile(np.eye(4), (len(rows), 1, 1))
+    P[:, :3, :4] = rows.reshape(-1, 3, 4)
+    if Tr is not None:
+        Ti = np.linalg.inv(Tr)
+        P = np.stack([Ti @ p @ Tr for p in P])
+    return P

@@ -33,3 +33,32 @@ def test_sequence_roundtrip(tmp_path):
     assert Tr.shape == (4, 4) and Tr[3, 3] == 1 and Tr[0, 3] == 0.1
     rows = kitti.poses_to_camera_frame([np.eye(4)], Tr)
     assert np.allclose(rows[0], np.eye(4)[:3].reshape(12))
+
+
+def test_devkit_odometry_errors_known_answers():
+    """the KITTI odometry devkit metric as the reference vendors it (src/util/kitti_utils.cpp:108-191), on trajectories
+    with known errors: none; a 1 % scale error (t_err = 0.01 exactly on a straight line); a constant yaw drift per metre"""
+    n = 900
+    gt = np.tile(np.eye(4), (n, 1, 1))
+    gt[:, 0, 3] = np.arange(n) * 1.0                       # 1 m per frame, straight
+    e = kitti.odometry_errors(gt, gt)
+    assert e["t_err"] == 0.0 and e["r_err"] == 0.0 and e["segments"] > 100 and set(e["per_length"]) == set(kitti.SEGMENT_LENGTHS)
+    scaled = gt.copy()
+    scaled[:, 0, 3] *= 1.01
+    e = kitti.odometry_errors(gt, scaled)
+    assert abs(e["t_err"] - 0.01) < 1e-3 and e["r_err"] < 1e-12   # the segment ends one frame behind the nominal length
+    # heading drifts by 1e-4 rad per metre: r_err = 1e-4 rad/m on every segment
+    drift = gt.copy()
+    for k in range(n):
+        a = 1e-4 * k
+        drift[k, :2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+    e = kitti.odometry_errors(gt, drift)
+    assert abs(e["r_err"] - 1e-4) < 2e-6
+    assert kitti.odometry_errors(gt[:50], gt[:50]) is None     # 49 m: no segment fits
+    # poses file round trip through the camera frame
+    Tr = np.array([[0, -1, 0, 0.1], [0, 0, -1, 0.2], [1, 0, 0, 0.3], [0, 0, 0, 1.0]])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        np.savetxt(os.path.join(d, "00.txt"), kitti.poses_to_camera_frame(drift[:20], Tr))
+        back = kitti.read_poses(os.path.join(d, "00.txt"), Tr)
+    assert np.allclose(back, drift[:20], atol=1e-9)
