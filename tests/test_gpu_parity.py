@@ -704,6 +704,26 @@ def test_loop_closure_verification(hip, oracle_lib, weight_function):
     assert fresh_differs == (weight_function == 2 and fresh_differs)  # Huber never reads the counter
 
 
+def test_pose_table_download(hip, oracle_lib):
+    """suma_map_download_poses = SurfelMap::poses_ (SurfelMap.h:205-208, written at SurfelMap.cpp:494-495): entry t is the
+    pose scan t was integrated with, as float -- the trajectory bench.py feeds to the KITTI devkit metric"""
+    p = params_with_size(900)
+    hp = hip.SurfelMapping(p)
+    op = oracle_lib.OraclePipeline(p)
+    assert hp.map.poses().shape == (0, 4, 4)
+    want = []
+    for k in range(5):
+        pts, lab, prob, _ = get_scan(k, 900, True)
+        hp.processScan(pts, lab, prob, fixed_iterations=6)
+        op.process_scan(pts, lab, prob, fixed_iterations=6)
+        want.append(hp.getCurrentPose().astype(np.float32))
+    got = hp.map.poses()
+    assert got.shape == (5, 4, 4) and got.dtype == np.float32
+    assert_bit_equal(got, np.stack(want), "pose table")
+    ora = op.ctx.map_poses(5).reshape(-1, 4, 4).transpose(0, 2, 1)
+    assert_bit_equal(got, ora, "pose table vs oracle")
+
+
 def _same_loop_results(a, b, what):
     assert len(a) == len(b)
     for k, (x, y) in enumerate(zip(a, b)):

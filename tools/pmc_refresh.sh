@@ -5,7 +5,7 @@
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 export SUMA_SCAN_CACHE=/tmp/suma_scans
-B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 --no-loop-closure"
+B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 --no-loop-closure --no-reference-mode"
 $B --steps 30 2>/dev/null | tail -1 | cut -c1-100
 for c in "pmc_fetch f FETCH_SIZE" "pmc_write w WRITE_SIZE" \
          "pmc_sq1 s SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVES" \

@@ -9,13 +9,13 @@
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 export SUMA_SCAN_CACHE=/tmp/suma_scans
-B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 --no-loop-closure"
+B="python bench.py --cpu-scans 0 --no-kernel-events --adapter-scans 0 --no-loop-closure --no-reference-mode"
 # the driver's exact command first (round-5 review item 3): -x, so that a failure anywhere shows as what the driver would record
 timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -4 > "$O/pytest_gpu.txt"
 timeout 600 python bench.py 2>"$O/bench.err" | tail -1 > "$O/bench.json"; cp gpurun_out/bench_kernels.json "$O/bench_kernels_hip_events.json"
 timeout 300 python bench.py --steps 20 2>"$O/bench_driver_shape.err" | tail -1 > "$O/bench_driver_shape_steps20.json"
 timeout 900 $B --no-host-vectors --steps 4541 --warmup 0 --preroll 0 --max-surfels 16777216 2>/dev/null | tail -1 > "$O/bench_full_sequence_4541.json"
-timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 --no-loop-closure 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 --no-loop-closure --no-reference-mode 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
 bash tools/pmc_refresh.sh "$TAG" > "$O/pmc_refresh.log" 2>&1
 timeout 400 python tools/stress_map.py 2>&1 | tail -1 > "$O/stress.json"
 # BASELINE configs[2] / configs[3] on ONE GPU (the driver owns the 8-GPU runs), the host-scan hand-over, 4 pipelines per GPU

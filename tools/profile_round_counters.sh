@@ -6,7 +6,7 @@
 TAG=${1:-round}
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"; O=gpurun_out/$TAG; mkdir -p "$O"
 export SUMA_SCAN_CACHE=/tmp/suma_scans
-timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 --no-loop-closure 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
+timeout 400 rocprofv3 --kernel-trace --stats -d "$O/prof" -o bench --output-format csv -- python bench.py --cpu-scans 0 --adapter-scans 0 --no-loop-closure --no-reference-mode 2>/dev/null | tail -1 > "$O/bench_under_rocprof.json"
 bash tools/pmc_refresh.sh "$TAG" > "$O/pmc_refresh.log" 2>&1
 f1() { find "$O/$1" -name "$2" | head -1; }
 python tools/rocprof_summary.py "$(f1 prof '*kernel_trace.csv')" > "$O/kernel_trace_summary.txt" 2>&1
