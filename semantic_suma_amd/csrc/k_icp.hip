@@ -420,7 +420,6 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
   __shared__ long long s_wave[ICP_THREADS / 64][SUMA_ACC_WORDS];
   __shared__ long long s_tot[ICP_THREADS / 32][SUMA_ACC_WORDS];
   __shared__ double s_pose[16], s_E[16], s_val[SUMA_ACC_WORDS];
-  __shared__ float s_posef[16]; /* pose_.cast<float>() for the pixel phase: the seven waves that waited read 64 bytes, not 128 + 16 conversions */
   __shared__ uint32_t s_flag[4]; /* done, iteration, history slot, last-block flag */
 
   if (blockIdx.x == 0 && threadIdx.x < ICP_RECORDS * SUMA_ACC_WORDS) /* for the next launch */
@@ -611,16 +610,13 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
           if (blockIdx.x == 0 && hist_slot != 0xffffffffu) g.history[16 * (size_t)hist_slot + lane] = t;
         }
         s_pose[lane] = t;
-        s_posef[lane] = (float)t;
         if (blockIdx.x == 0) gout->Tk[lane] = t;
       }
     }
     GN_STAMP(4); /* wave 0: exp + pose product + state stores issued */
     __syncthreads();
-    if (!PIXEL) { /* only the closing launch needs the doubles (pose emit, host record) */
 #pragma unroll
-      for (int i = 0; i < 16; ++i) Tk[i] = s_pose[i];
-    }
+    for (int i = 0; i < 16; ++i) Tk[i] = s_pose[i];
     done = s_flag[0];
     iteration = s_flag[1];
   } else if (writer && g.init) {
@@ -704,14 +700,12 @@ __device__ __forceinline__ void icp_iter_body(const IterArgs& g, const uint32_t 
   }
 
   /* ---- K6 pixel phase at the current pose ---- */
-  float T[16]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
-  if (pending) {
+  /* (Round 6 handed the pose to the waiting waves as 16 floats through a second LDS array: k_icp_step -1 % for one chain,
+   * but 129 instead of 123 VGPRs -- over the 128 that let two 512-thread blocks share a CU, and batched chains, which
+   * fill the chip, lost 19 % (BASELINE configs[2]: 1420 -> 1196 scans/s).  Not kept: profiles/r06_gn_pixel_phase.txt.) */
+  float T[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = s_posef[i];
-  } else {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) T[i] = (float)Tk[i];
-  }
+  for (int i = 0; i < 16; ++i) T[i] = (float)Tk[i]; /* pose_.cast<float>(), Frame2Model.cpp:194 */
 
   /* Per trip the 32 terms of a pixel are formed and wave-reduced in two halves of 16 words: a lane never holds more
    * than 16 int64 terms (32 VGPRs instead of 64), and what it carries from trip to trip is the wave total of ONE word
